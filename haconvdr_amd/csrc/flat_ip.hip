@@ -1,0 +1,946 @@
+// Exact inner-product top-k search for gfx950 (MI355X): the faiss.IndexFlatIP
+// replacement behind hac_index_* (include/haconvdr.h).
+//
+// Reference path replaced: src/test_HAConvDR_topiocqa.py:52 (IndexFlatIP(768)),
+// :98 add, :102 search, :122 reset, :110 id remap, :126-149 block merge.
+//
+// Design:
+//   * HBM layout "T64": the corpus is re-tiled at add() into groups of 64 rows;
+//     inside a group chunk t (t = 0..d/4-1) is 1 KiB holding, for lane l = row l of
+//     the group, the four floats x[row][4t..4t+3].  One dwordx4 load per lane is a
+//     fully coalesced 1-KiB wave access AND already the A operand (4 k-steps) of
+//     v_mfma_f32_16x16x1_4b_f32 — no LDS staging, no shuffles for the corpus.
+//   * Scores are exact fp32: the MFMA's per-element arithmetic is the k-ordered
+//     fmaf chain (verified bit-for-bit on MI355X), identical to the CPU oracle.
+//   * One workgroup (4 waves) keeps <=16 queries in LDS ([d/4][QT] float4, the B
+//     operand, conflict-free ds_read_b128) and streams groups; each wave owns one
+//     64-row group per round.  Output tile: lane -> query (lane&15), 16 regs -> rows.
+//   * Top-k: scores pass a per-query threshold (a proven lower bound of the final
+//     k-th score: seeded from an exact top-k of a corpus sample, raised by local
+//     compactions and a chip-wide atomicMax), survivors are appended to per-query
+//     LDS candidate buffers as 64-bit keys (orderable score << 32 | ~position) and
+//     compacted by an in-LDS wave-level bitonic sort.  Per-workgroup top-k lists
+//     are merged by a second kernel.  The result is independent of timing: the
+//     total order on keys is strict and the threshold never exceeds the true k-th.
+#include "hac_common.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace hac {
+
+std::string &last_error_slot() {
+    static thread_local std::string s;
+    return s;
+}
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    last_error_slot() = buf;
+    return code;
+}
+
+namespace {
+
+constexpr int GROUP_ROWS = 64;
+constexpr int SCAN_WAVES = 4;          // waves per scan workgroup
+constexpr int PF = 8;                  // 1-KiB chunks in flight per wave
+constexpr int MAX_SEG = 64;
+constexpr int MERGE_THREADS = 256;
+constexpr size_t LDS_LIMIT = 160 * 1024;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct SegDesc {
+    const float4 *ptr;  // tiled rows of this segment
+    u32 gstart;         // first global group index of this segment
+    u32 pad;
+};
+
+// ------------------------------------------------------------------ key packing
+__device__ __forceinline__ u32 f2ord(float f) {
+    u32 b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(u32 o) {
+    u32 b = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __uint_as_float(b);
+}
+__device__ __forceinline__ u64 make_key(float s, u32 pos) {
+    s = s + 0.0f;  // -0.0 -> +0.0 so that key order == (score desc, pos asc) under float compare
+    return ((u64)f2ord(s) << 32) | (u64)(0xFFFFFFFFu - pos);
+}
+
+__device__ __forceinline__ void lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
+
+// In-LDS bitonic sort, descending, by ONE wave.  buf has capacity >= next_pow2(n).
+__device__ void wave_sort_desc(u64 *buf, u32 n, int lane) {
+    u32 np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    for (u32 i = n + lane; i < np2; i += 64) buf[i] = 0;
+    lds_fence();
+    for (u32 size = 2; size <= np2; size <<= 1) {
+        for (u32 stride = size >> 1; stride > 0; stride >>= 1) {
+            for (u32 t = lane; t < (np2 >> 1); t += 64) {
+                u32 lo = 2 * t - (t & (stride - 1));
+                u32 hi = lo + stride;
+                bool desc = (lo & size) == 0;
+                u64 a = buf[lo], b = buf[hi];
+                if ((a < b) == desc) {
+                    buf[lo] = b;
+                    buf[hi] = a;
+                }
+            }
+            lds_fence();
+        }
+    }
+}
+
+// Same, by a whole workgroup (blockDim.x threads); all threads must call it.
+__device__ void block_sort_desc(u64 *buf, u32 n, int tid, int nthreads) {
+    u32 np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    for (u32 i = n + tid; i < np2; i += nthreads) buf[i] = 0;
+    __syncthreads();
+    for (u32 size = 2; size <= np2; size <<= 1) {
+        for (u32 stride = size >> 1; stride > 0; stride >>= 1) {
+            for (u32 t = tid; t < (np2 >> 1); t += nthreads) {
+                u32 lo = 2 * t - (t & (stride - 1));
+                u32 hi = lo + stride;
+                bool desc = (lo & size) == 0;
+                u64 a = buf[lo], b = buf[hi];
+                if ((a < b) == desc) {
+                    buf[lo] = b;
+                    buf[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------ re-tiling
+// Row-major rows -> T64 tiles.  One workgroup per destination group touched by
+// segment rows [row0, row0 + m).  Reads are row-contiguous (256 B per 16 lanes),
+// writes are whole 1-KiB chunks; the transpose goes through a padded LDS tile.
+__global__ __launch_bounds__(256) void tile_rows_kernel(const float4 *__restrict__ src, long m, int K4,
+                                                        float4 *__restrict__ seg, long row0) {
+    __shared__ float4 tile[16][65];
+    const int tid = threadIdx.x;
+    const long gd = row0 / GROUP_ROWS + blockIdx.x;
+    const long r_lo = max(row0, gd * GROUP_ROWS), r_hi = min(row0 + m, gd * GROUP_ROWS + GROUP_ROWS);
+    float4 *dst = seg + gd * (long)K4 * GROUP_ROWS;
+    for (int k4b = 0; k4b < K4; k4b += 16) {
+        for (int i = tid; i < 1024; i += 256) {
+            const int r = i >> 4, c = i & 15;
+            const long dr = gd * GROUP_ROWS + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (dr >= r_lo && dr < r_hi && k4b + c < K4) v = src[(dr - row0) * K4 + k4b + c];
+            tile[c][r] = v;
+        }
+        __syncthreads();
+        for (int i = tid; i < 1024; i += 256) {
+            const int c = i >> 6, r = i & 63;
+            const long dr = gd * GROUP_ROWS + r;
+            if (dr >= r_lo && dr < r_hi && k4b + c < K4) dst[(long)(k4b + c) * GROUP_ROWS + r] = tile[c][r];
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ scan kernel
+struct ScanArgs {
+    const SegDesc *segs;
+    int nseg;
+    const float4 *q;        // [nq][K4] row-major queries
+    int nq, K4, k, C, QT;   // C: candidate slots per query (pow2 >= k + 64*SCAN_WAVES); QT queries per workgroup
+    long n_rows;            // valid rows in the index
+    u32 g_first, g_step, n_items;  // work items i -> group g_first + i*g_step
+    const float *thr_init;  // [nq] lower bounds of the final k-th score, or null
+    u32 *thr_glob;          // [nq] chip-wide threshold, orderable-uint encoding, 0 = none
+    u64 *partial;           // [nq][gridDim.x][k] per-workgroup sorted lists
+    u32 pos_base;
+};
+
+__device__ __forceinline__ const float4 *group_ptr(const ScanArgs &a, u32 g) {
+    int s = 0;
+    while (s + 1 < a.nseg && g >= a.segs[s + 1].gstart) ++s;
+    return a.segs[s].ptr + (size_t)(g - a.segs[s].gstart) * a.K4 * GROUP_ROWS;
+}
+
+#define HAC_MFMA4(av, bv)                                                        \
+    acc = __builtin_amdgcn_mfma_f32_16x16x1f32((av).x, (bv).x, acc, 0, 0, 0);    \
+    acc = __builtin_amdgcn_mfma_f32_16x16x1f32((av).y, (bv).y, acc, 0, 0, 0);    \
+    acc = __builtin_amdgcn_mfma_f32_16x16x1f32((av).z, (bv).z, acc, 0, 0, 0);    \
+    acc = __builtin_amdgcn_mfma_f32_16x16x1f32((av).w, (bv).w, acc, 0, 0, 0);
+
+__global__ __launch_bounds__(SCAN_WAVES * 64) void scan16_kernel(ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K4 = a.K4;
+    const int q0 = blockIdx.y * a.QT;
+    const int QTr = min(a.QT, a.nq - q0);
+    const int C = a.C;
+
+    float4 *ldsQ = reinterpret_cast<float4 *>(smem);                       // [K4][QTr]
+    u64 *cand = reinterpret_cast<u64 *>(smem + (size_t)K4 * QTr * 16);     // [QTr][C]
+    u32 *cnt = reinterpret_cast<u32 *>(cand + (size_t)QTr * C);            // [16]
+    float *thr = reinterpret_cast<float *>(cnt + 16);                      // [16]
+
+    for (int idx = tid; idx < K4 * QTr; idx += SCAN_WAVES * 64) {
+        const int k4 = idx / QTr, j = idx - k4 * QTr;
+        ldsQ[idx] = a.q[(size_t)(q0 + j) * K4 + k4];
+    }
+    if (tid < 16) {
+        cnt[tid] = 0;
+        thr[tid] = (tid < QTr && a.thr_init) ? a.thr_init[q0 + tid] : -INFINITY;
+    }
+    __syncthreads();
+
+    const int j = lane & 15;
+    const int jc = min(j, QTr - 1);
+    const float4 *qb = ldsQ + jc;
+    const u32 stride = gridDim.x * SCAN_WAVES;
+    const u32 nrounds = (a.n_items + stride - 1) / stride;
+    const u32 hw = (u32)C - 64u * SCAN_WAVES;  // compaction high-water mark (>= k)
+
+    u32 item = blockIdx.x * SCAN_WAVES + w;
+    bool have = item < a.n_items;
+    const float4 *gp = group_ptr(a, a.g_first + (have ? item : 0) * a.g_step) + lane;
+    float4 ring[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) ring[i] = gp[i * 64];
+
+    for (u32 r = 0; r < nrounds; ++r) {
+        const u32 g = a.g_first + item * a.g_step;
+        const u32 nitem = item + stride;
+        const bool have_next = nitem < a.n_items;
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (have) {
+            const float4 *np = have_next ? group_ptr(a, a.g_first + nitem * a.g_step) + lane : gp;
+            const int NB = K4 / PF;
+            for (int tb = 0; tb < NB - 1; ++tb) {
+#pragma unroll
+                for (int i = 0; i < PF; ++i) {
+                    const int t = tb * PF + i;
+                    const float4 av = ring[i];
+                    ring[i] = gp[(t + PF) * 64];
+                    const float4 bv = qb[t * QTr];
+                    HAC_MFMA4(av, bv)
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const int t = (NB - 1) * PF + i;
+                const float4 av = ring[i];
+                ring[i] = np[i * 64];  // next group's first chunks stay in flight across the epilogue
+                const float4 bv = qb[t * QTr];
+                HAC_MFMA4(av, bv)
+            }
+            gp = np;
+        }
+
+        __syncthreads();  // (A) last round's compactions are complete
+        if (have) {
+            const float th = thr[jc];
+            bool anyp = false;
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) anyp |= (acc[rr] >= th);
+            if (__any(anyp)) {
+                const long rem = a.n_rows - (long)g * GROUP_ROWS;
+                const int rows_valid = rem < GROUP_ROWS ? (int)rem : GROUP_ROWS;
+                const int rbase = 4 * (lane >> 4);
+                if (j < QTr) {
+#pragma unroll
+                    for (int rr = 0; rr < 16; ++rr) {
+                        const int row = 16 * (rr >> 2) + rbase + (rr & 3);
+                        const float s = acc[rr];
+                        if (s >= th && row < rows_valid) {
+                            const u32 pos = atomicAdd(&cnt[j], 1u);
+                            cand[(size_t)j * C + pos] = make_key(s, a.pos_base + g * GROUP_ROWS + row);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();  // (B) all appends of this round are visible
+        for (int jj = w; jj < QTr; jj += SCAN_WAVES) {
+            const u32 n = cnt[jj];
+            float t_new = -INFINITY;
+            if (n > hw) {  // wave-uniform
+                wave_sort_desc(cand + (size_t)jj * C, n, lane);
+                t_new = ord2f((u32)(cand[(size_t)jj * C + a.k - 1] >> 32));
+            }
+            if (lane == 0) {
+                float t_cur = thr[jj];
+                if (n > hw) {
+                    cnt[jj] = a.k;
+                    if (t_new > t_cur) {
+                        t_cur = t_new;
+                        atomicMax(&a.thr_glob[q0 + jj], f2ord(t_new));
+                    }
+                }
+                const u32 go = __hip_atomic_load(&a.thr_glob[q0 + jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (go != 0u) t_cur = fmaxf(t_cur, ord2f(go));
+                thr[jj] = t_cur;
+            }
+        }
+        item = nitem;
+        have = have_next;
+    }
+
+    __syncthreads();
+    for (int jj = w; jj < QTr; jj += SCAN_WAVES) {
+        const u32 n = cnt[jj];
+        u64 *b = cand + (size_t)jj * C;
+        if (n > 1) wave_sort_desc(b, n, lane);
+        u64 *out = a.partial + ((size_t)(q0 + jj) * gridDim.x + blockIdx.x) * a.k;
+        const u32 keep = n < (u32)a.k ? n : (u32)a.k;
+        for (u32 i = lane; i < (u32)a.k; i += 64) out[i] = i < keep ? b[i] : 0ull;
+    }
+}
+
+// ------------------------------------------------------------------ merge kernel
+// One workgroup per query: streams L lists of k keys, keeps the k largest.
+// Element (l, q, i) lives at lists[l*stride_l + q*stride_q + i].
+__global__ __launch_bounds__(MERGE_THREADS) void merge_keys_kernel(const u64 *__restrict__ lists, int L,
+                                                                   size_t stride_l, size_t stride_q, int k, int Cm,
+                                                                   u64 *__restrict__ out, float *__restrict__ kth_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64 *buf = reinterpret_cast<u64 *>(smem);          // [Cm]
+    u32 *cnt = reinterpret_cast<u32 *>(buf + Cm);      // [1]
+    u64 *thrk = reinterpret_cast<u64 *>(cnt + 2);      // [1]
+    const int tid = threadIdx.x;
+    const size_t q = blockIdx.x;
+    if (tid == 0) {
+        *cnt = 0;
+        *thrk = 0;
+    }
+    __syncthreads();
+    const long total = (long)L * k;
+    for (long base = 0; base < total; base += MERGE_THREADS) {
+        const long idx = base + tid;
+        u64 key = 0;
+        if (idx < total) {
+            const long l = idx / k;
+            const int i = (int)(idx - l * k);
+            key = lists[(size_t)l * stride_l + q * stride_q + i];
+        }
+        if (key > *thrk) {
+            const u32 pos = atomicAdd(cnt, 1u);
+            buf[pos] = key;
+        }
+        __syncthreads();
+        const u32 n = *cnt;
+        __syncthreads();  // nobody appends for the next chunk before everyone has read n
+        if (n > (u32)(Cm - MERGE_THREADS)) {  // uniform
+            block_sort_desc(buf, n, tid, MERGE_THREADS);
+            if (tid == 0) {
+                *cnt = k;
+                *thrk = buf[k - 1];
+            }
+            __syncthreads();
+        }
+    }
+    const u32 n = *cnt;
+    if (n > 1) block_sort_desc(buf, n, tid, MERGE_THREADS);
+    const u32 keep = n < (u32)k ? n : (u32)k;
+    for (u32 i = tid; i < (u32)k; i += MERGE_THREADS) out[q * k + i] = i < keep ? buf[i] : 0ull;
+    if (kth_out && tid == 0) kth_out[q] = (n >= (u32)k) ? ord2f((u32)(buf[k - 1] >> 32)) : -INFINITY;
+}
+
+// keys -> faiss-style (D, I); empty slots: -FLT_MAX / -1
+__global__ void keys_to_results_kernel(const u64 *__restrict__ keys, long n, const long long *__restrict__ id_map,
+                                       float *__restrict__ D, long long *__restrict__ I) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 key = keys[i];
+    if (key == 0ull) {
+        D[i] = -FLT_MAX;
+        I[i] = -1;
+    } else {
+        const u32 pos = 0xFFFFFFFFu - (u32)key;
+        D[i] = ord2f((u32)(key >> 32));
+        I[i] = id_map ? id_map[pos] : (long long)pos;
+    }
+}
+
+u32 next_pow2(u32 v) {
+    u32 p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// ------------------------------------------------------------------ one-device index
+struct Segment {
+    float4 *buf = nullptr;
+    int64_t cap_rows = 0;  // multiple of 64
+    int64_t rows = 0;
+};
+
+struct DeviceIndex {
+    int d = 0, K4 = 0, device = 0, n_cu = 256;
+    hipStream_t stream = nullptr;  // for the synchronous host API
+    std::vector<Segment> segs;
+    int64_t ntotal = 0;
+    SegDesc *d_segs = nullptr;
+    bool segs_dirty = true;
+    GrowBuf ws_partial, ws_seedkeys, ws_thr, ws_thrglob, ws_q, ws_keys, ws_D, ws_I, ws_stage[2];
+    void *h_stage[2] = {nullptr, nullptr};
+    size_t h_stage_bytes = 0;
+    // Small host<->device traffic (queries, results, segment table) always goes through
+    // pinned memory: pageable hipMemcpyAsync is not reliably stream-ordered on this stack.
+    void *h_pin = nullptr;
+    size_t h_pin_bytes = 0;
+    SegDesc *h_segs = nullptr;
+    int pin_reserve(size_t bytes) {
+        if (bytes <= h_pin_bytes) return HAC_OK;
+        if (h_pin) (void)hipHostFree(h_pin);
+        h_pin = nullptr;
+        h_pin_bytes = 0;
+        hipError_t e = hipHostMalloc(&h_pin, bytes + bytes / 4, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(HAC_ERR_OOM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        h_pin_bytes = bytes + bytes / 4;
+        return HAC_OK;
+    }
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    bool profiling = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+
+    int init(int d_, int device_) {
+        d = d_;
+        K4 = d / 4;
+        device = device_;
+        DeviceGuard g(device);
+        if (!g.ok) return fail(HAC_ERR_HIP, "cannot select HIP device %d (no MI355X visible?)", device);
+        hipDeviceProp_t prop;
+        HAC_HIP(hipGetDeviceProperties(&prop, device));
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        HAC_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        HAC_HIP(hipMalloc((void **)&d_segs, sizeof(SegDesc) * MAX_SEG));
+        HAC_HIP(hipHostMalloc((void **)&h_segs, sizeof(SegDesc) * MAX_SEG, hipHostMallocDefault));
+        HAC_HIP(hipEventCreate(&ev0));
+        HAC_HIP(hipEventCreate(&ev1));
+        for (int i = 0; i < 2; ++i) HAC_HIP(hipEventCreateWithFlags(&stage_ev[i], hipEventDisableTiming));
+        static bool attr_done[64] = {false};
+        if (device < 64 && !attr_done[device]) {
+            HAC_HIP(hipFuncSetAttribute((const void *)scan16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)LDS_LIMIT));
+            HAC_HIP(hipFuncSetAttribute((const void *)merge_keys_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)(64 * 1024)));
+            attr_done[device] = true;
+        }
+        return HAC_OK;
+    }
+
+    void destroy() {
+        DeviceGuard g(device);
+        if (stream) (void)hipStreamSynchronize(stream);
+        for (auto &s : segs)
+            if (s.buf) (void)hipFree(s.buf);
+        segs.clear();
+        if (d_segs) (void)hipFree(d_segs);
+        if (h_segs) (void)hipHostFree(h_segs);
+        if (h_pin) (void)hipHostFree(h_pin);
+        for (GrowBuf *b : {&ws_partial, &ws_seedkeys, &ws_thr, &ws_thrglob, &ws_q, &ws_keys, &ws_D, &ws_I, &ws_stage[0],
+                           &ws_stage[1]})
+            b->release();
+        for (int i = 0; i < 2; ++i) {
+            if (h_stage[i]) (void)hipHostFree(h_stage[i]);
+            if (stage_ev[i]) (void)hipEventDestroy(stage_ev[i]);
+        }
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+
+    int reset() {
+        DeviceGuard g(device);
+        HAC_HIP(hipStreamSynchronize(stream));
+        // keep the largest allocation for reuse (the reference resets after every block, :122)
+        size_t best = 0;
+        for (size_t i = 1; i < segs.size(); ++i)
+            if (segs[i].cap_rows > segs[best].cap_rows) best = i;
+        std::vector<Segment> keep;
+        for (size_t i = 0; i < segs.size(); ++i) {
+            if (i == best) {
+                Segment s = segs[i];
+                s.rows = 0;
+                keep.push_back(s);
+            } else if (segs[i].buf) {
+                HAC_HIP(hipFree(segs[i].buf));
+            }
+        }
+        segs.swap(keep);
+        ntotal = 0;
+        segs_dirty = true;
+        return HAC_OK;
+    }
+
+    // make room for m more rows: returns (segment index) whose rows..cap_rows can take them in pieces
+    int new_segment(int64_t rows_needed, hipStream_t st) {
+        if ((int)segs.size() >= MAX_SEG) HAC_TRY(consolidate(st));
+        Segment s;
+        s.cap_rows = (rows_needed + GROUP_ROWS - 1) / GROUP_ROWS * GROUP_ROWS;
+        const size_t bytes = (size_t)s.cap_rows * d * sizeof(float);
+        hipError_t e = hipMalloc((void **)&s.buf, bytes);
+        if (e != hipSuccess) return fail(HAC_ERR_OOM, "hipMalloc(%zu) for %lld rows failed: %s", bytes, (long long)rows_needed, hipGetErrorString(e));
+        // zero the last group so that padding rows are finite
+        const size_t gbytes = (size_t)GROUP_ROWS * d * sizeof(float);
+        HAC_HIP(hipMemsetAsync((char *)s.buf + bytes - gbytes, 0, gbytes, st));
+        segs.push_back(s);
+        return HAC_OK;
+    }
+
+    // fuse all segments into one allocation (groups are self-contained, so this is plain copies)
+    int consolidate(hipStream_t st) {
+        int64_t total_cap = 0;
+        for (auto &s : segs) total_cap += (s.rows + GROUP_ROWS - 1) / GROUP_ROWS * GROUP_ROWS;
+        Segment big;
+        big.cap_rows = total_cap;
+        HAC_HIP(hipMalloc((void **)&big.buf, (size_t)total_cap * d * sizeof(float)));
+        int64_t off_rows = 0;
+        for (auto &s : segs) {
+            const int64_t gr = (s.rows + GROUP_ROWS - 1) / GROUP_ROWS * GROUP_ROWS;
+            if (gr) HAC_HIP(hipMemcpyAsync((char *)big.buf + (size_t)off_rows * d * 4, s.buf, (size_t)gr * d * 4, hipMemcpyDeviceToDevice, st));
+            off_rows += gr;
+            big.rows += s.rows;
+        }
+        HAC_HIP(hipStreamSynchronize(st));
+        for (auto &s : segs) HAC_HIP(hipFree(s.buf));
+        segs.clear();
+        segs.push_back(big);
+        segs_dirty = true;
+        return HAC_OK;
+    }
+
+    // src_dev: row-major [n][d] on this device.  Appends rows in dense numbering: every
+    // segment but the last holds a multiple of 64 rows.
+    int add_device_rows(const float *src_dev, int64_t n, hipStream_t st, int64_t reserve_hint = 0) {
+        if (((uintptr_t)src_dev & 15) != 0) return fail(HAC_ERR_INVALID, "add: device pointer must be 16-byte aligned");
+        int64_t done = 0;
+        while (done < n) {
+            if (segs.empty() || segs.back().rows == segs.back().cap_rows) {
+                // a fresh segment must start on a group boundary of the global numbering
+                if (!segs.empty() && segs.back().rows % GROUP_ROWS != 0) return fail(HAC_ERR_INVALID, "internal: partial segment");
+                HAC_TRY(new_segment(std::max(n, reserve_hint) - done, st));
+            }
+            Segment &s = segs.back();
+            const int64_t m = std::min(n - done, s.cap_rows - s.rows);
+            const long row0 = (long)s.rows;
+            const long g_lo = row0 / GROUP_ROWS, g_hi = (row0 + m + GROUP_ROWS - 1) / GROUP_ROWS;
+            tile_rows_kernel<<<dim3((unsigned)(g_hi - g_lo)), dim3(256), 0, st>>>(
+                reinterpret_cast<const float4 *>(src_dev + (size_t)done * d), (long)m, K4, s.buf, row0);
+            HAC_HIP(hipGetLastError());
+            s.rows += m;
+            done += m;
+        }
+        ntotal += n;
+        segs_dirty = true;
+        return HAC_OK;
+    }
+
+    int add_host_rows(const float *x, int64_t n) {
+        DeviceGuard g(device);
+        const int64_t chunk_rows = std::max<int64_t>(GROUP_ROWS, (int64_t)(64u << 20) / (d * 4) / GROUP_ROWS * GROUP_ROWS);  // ~64 MiB
+        const size_t chunk_bytes = (size_t)chunk_rows * d * 4;
+        if (h_stage_bytes < chunk_bytes) {
+            for (int i = 0; i < 2; ++i) {
+                if (h_stage[i]) (void)hipHostFree(h_stage[i]);
+                h_stage[i] = nullptr;
+                hipError_t e = hipHostMalloc(&h_stage[i], chunk_bytes, hipHostMallocDefault);
+                if (e != hipSuccess) return fail(HAC_ERR_OOM, "hipHostMalloc(%zu) failed: %s", chunk_bytes, hipGetErrorString(e));
+            }
+            h_stage_bytes = chunk_bytes;
+        }
+        for (int i = 0; i < 2; ++i) HAC_TRY(ws_stage[i].reserve(chunk_bytes));
+        int64_t done = 0;
+        int slot = 0;
+        bool used[2] = {false, false};
+        while (done < n) {
+            const int64_t m = std::min(chunk_rows, n - done);
+            if (used[slot]) HAC_HIP(hipEventSynchronize(stage_ev[slot]));
+            std::memcpy(h_stage[slot], x + (size_t)done * d, (size_t)m * d * 4);
+            HAC_HIP(hipMemcpyAsync(ws_stage[slot].p, h_stage[slot], (size_t)m * d * 4, hipMemcpyHostToDevice, stream));
+            // one new segment per add() at most: size it for everything that is left
+            HAC_TRY(add_device_rows((const float *)ws_stage[slot].p, m, stream, n - done));
+            HAC_HIP(hipEventRecord(stage_ev[slot], stream));
+            used[slot] = true;
+            slot ^= 1;
+            done += m;
+        }
+        HAC_HIP(hipStreamSynchronize(stream));
+        return HAC_OK;
+    }
+
+    int upload_segs(hipStream_t st) {
+        if (!segs_dirty) return HAC_OK;
+        // h_segs may still be the source of an earlier in-flight copy on another stream
+        HAC_HIP(hipStreamSynchronize(st));
+        SegDesc *h = h_segs;
+        u32 g = 0;
+        int n = 0;
+        for (auto &s : segs) {
+            if (s.rows == 0) continue;
+            h[n].ptr = s.buf;
+            h[n].gstart = g;
+            h[n].pad = 0;
+            g += (u32)((s.rows + GROUP_ROWS - 1) / GROUP_ROWS);
+            ++n;
+        }
+        if (n) HAC_HIP(hipMemcpyAsync(d_segs, h, sizeof(SegDesc) * n, hipMemcpyHostToDevice, st));
+        nseg_live = n;
+        segs_dirty = false;
+        return HAC_OK;
+    }
+    int nseg_live = 0;
+
+    struct Plan {
+        int QT, C, n_qtiles, P, Cm;
+        size_t lds_scan, lds_merge;
+    };
+
+    int make_plan(int64_t nq, int k, u32 n_items, Plan &pl) const {
+        pl.C = (int)next_pow2((u32)k + 64u * SCAN_WAVES);
+        const size_t per_q = (size_t)K4 * 16 + (size_t)pl.C * 8;
+        const size_t fixed = 16 * 4 + 16 * 4;
+        int qt = (int)std::min<size_t>(16, (LDS_LIMIT - fixed) / per_q);
+        if (qt < 1) return fail(HAC_ERR_UNSUPPORTED, "k=%d with d=%d does not fit the LDS candidate buffers", k, d);
+        qt = (int)std::min<int64_t>(qt, nq);
+        pl.QT = qt;
+        pl.lds_scan = per_q * qt + fixed;
+        pl.n_qtiles = (int)((nq + qt - 1) / qt);
+        // resident workgroups: LDS- and wave-limited
+        int per_cu = (int)std::min<size_t>(LDS_LIMIT / pl.lds_scan, 32 / SCAN_WAVES);
+        per_cu = std::max(1, std::min(per_cu, 4));
+        const long resident = (long)n_cu * per_cu;
+        long P = std::max<long>(1, resident / pl.n_qtiles);
+        if (P >= 8) P = P / 8 * 8;  // same-row workgroups of different query tiles share an XCD (L2)
+        const long maxP = (n_items + SCAN_WAVES - 1) / SCAN_WAVES;
+        P = std::max<long>(1, std::min(P, maxP));
+        pl.P = (int)P;
+        pl.Cm = (int)next_pow2((u32)k + MERGE_THREADS);
+        pl.lds_merge = (size_t)pl.Cm * 8 + 32;
+        return HAC_OK;
+    }
+
+    int run_scan(const Plan &pl, const float *q_dev, int64_t nq, int k, u32 g_first, u32 g_step, u32 n_items,
+                 const float *thr_init, u32 pos_base, int P, hipStream_t st, bool timed) {
+        ScanArgs a;
+        a.segs = d_segs;
+        a.nseg = nseg_live;
+        a.q = reinterpret_cast<const float4 *>(q_dev);
+        a.nq = (int)nq;
+        a.K4 = K4;
+        a.k = k;
+        a.C = pl.C;
+        a.QT = pl.QT;
+        a.n_rows = (long)ntotal;
+        a.g_first = g_first;
+        a.g_step = g_step;
+        a.n_items = n_items;
+        a.thr_init = thr_init;
+        a.thr_glob = (u32 *)ws_thrglob.p;
+        a.partial = (u64 *)ws_partial.p;
+        a.pos_base = pos_base;
+        HAC_HIP(hipMemsetAsync(ws_thrglob.p, 0, (size_t)nq * 4, st));
+        if (timed) HAC_HIP(hipEventRecord(ev0, st));
+        scan16_kernel<<<dim3((unsigned)P, (unsigned)pl.n_qtiles), dim3(SCAN_WAVES * 64), pl.lds_scan, st>>>(a);
+        HAC_HIP(hipGetLastError());
+        if (timed) {
+            HAC_HIP(hipEventRecord(ev1, st));
+            ev_valid = true;
+        }
+        return HAC_OK;
+    }
+
+    int run_merge(const Plan &pl, const u64 *lists, int L, size_t stride_l, size_t stride_q, int64_t nq, int k,
+                  u64 *out, float *kth_out, hipStream_t st) {
+        merge_keys_kernel<<<dim3((unsigned)nq), dim3(MERGE_THREADS), pl.lds_merge, st>>>(lists, L, stride_l, stride_q, k,
+                                                                                         pl.Cm, out, kth_out);
+        HAC_HIP(hipGetLastError());
+        return HAC_OK;
+    }
+
+    // keys_out: device u64 [nq][k]
+    int search_keys(const float *q_dev, int64_t nq, int k, u64 *keys_out, u32 pos_base, hipStream_t st) {
+        if (nq == 0) return HAC_OK;
+        if (((uintptr_t)q_dev & 15) != 0) return fail(HAC_ERR_INVALID, "search: query pointer must be 16-byte aligned");
+        if ((uint64_t)pos_base + (uint64_t)ntotal > 0xFFFFFFFFull) return fail(HAC_ERR_UNSUPPORTED, "row positions exceed 32 bits");
+        if (ntotal == 0) {
+            HAC_HIP(hipMemsetAsync(keys_out, 0, (size_t)nq * k * 8, st));
+            return HAC_OK;
+        }
+        HAC_TRY(upload_segs(st));
+        const u32 G = (u32)((ntotal + GROUP_ROWS - 1) / GROUP_ROWS);
+        Plan pl;
+        HAC_TRY(make_plan(nq, k, G, pl));
+        HAC_TRY(ws_partial.reserve((size_t)nq * pl.P * k * 8));
+        HAC_TRY(ws_thrglob.reserve((size_t)nq * 4));
+        const float *thr_init = nullptr;
+        // Threshold seeding: exact top-k of an evenly strided sample of groups gives a
+        // lower bound of every query's final k-th score; it only filters, never decides.
+        const u32 n_sample = std::max<u32>(256u, G / 64u);
+        if (G >= 4u * n_sample && (int64_t)n_sample * GROUP_ROWS >= 4 * (int64_t)k) {
+            HAC_TRY(ws_seedkeys.reserve((size_t)nq * k * 8));
+            HAC_TRY(ws_thr.reserve((size_t)nq * 4));
+            const u32 step = G / n_sample;
+            const int Ps = (int)std::max<long>(1, std::min<long>(pl.P, (n_sample + SCAN_WAVES - 1) / SCAN_WAVES));
+            HAC_TRY(run_scan(pl, q_dev, nq, k, 0, step, n_sample, nullptr, pos_base, Ps, st, false));
+            HAC_TRY(run_merge(pl, (const u64 *)ws_partial.p, Ps, (size_t)k, (size_t)Ps * k, nq, k, (u64 *)ws_seedkeys.p,
+                              (float *)ws_thr.p, st));
+            thr_init = (const float *)ws_thr.p;
+        }
+        HAC_TRY(run_scan(pl, q_dev, nq, k, 0, 1, G, thr_init, pos_base, pl.P, st, profiling));
+        HAC_TRY(run_merge(pl, (const u64 *)ws_partial.p, pl.P, (size_t)k, (size_t)pl.P * k, nq, k, keys_out, nullptr, st));
+        return HAC_OK;
+    }
+};
+
+int merge_plan_lds(int k, int &Cm, size_t &lds) {
+    Cm = (int)next_pow2((u32)k + MERGE_THREADS);
+    lds = (size_t)Cm * 8 + 32;
+    return HAC_OK;
+}
+
+int check_k(int k) {
+    if (k < 1 || k > HAC_MAX_K) return fail(HAC_ERR_INVALID, "k=%d out of range [1, %d]", k, HAC_MAX_K);
+    return HAC_OK;
+}
+
+}  // namespace
+}  // namespace hac
+
+// =============================================================================
+// C ABI
+// =============================================================================
+using namespace hac;
+
+struct hac_index {
+    int d = 0;
+    std::vector<DeviceIndex *> shards;  // one per device (n_dev == 1 in the one-process-per-GPU deployment)
+    int64_t ntotal = 0;
+    // multi-device merge workspace lives on shard 0
+    GrowBuf ws_lists, ws_out;
+};
+
+extern "C" {
+
+const char *hac_last_error(void) { return last_error_slot().c_str(); }
+const char *hac_version(void) { return "haconvdr-amd 0.1.0 (gfx950)"; }
+
+int hac_index_create(int d, const int *device_ids, int n_dev, hac_index **out) {
+    if (!out) return fail(HAC_ERR_INVALID, "hac_index_create: out is null");
+    *out = nullptr;
+    if (d <= 0 || d % 32 != 0 || d > HAC_MAX_D) return fail(HAC_ERR_INVALID, "d=%d must be a positive multiple of 32, <= %d", d, HAC_MAX_D);
+    if (n_dev < 1 || !device_ids) return fail(HAC_ERR_INVALID, "need at least one device id");
+    int n_visible = 0;
+    if (hipGetDeviceCount(&n_visible) != hipSuccess || n_visible <= 0)
+        return fail(HAC_ERR_HIP, "no HIP device visible: the haconvdr search path has no CPU fallback");
+    for (int i = 0; i < n_dev; ++i)
+        if (device_ids[i] < 0 || device_ids[i] >= n_visible) return fail(HAC_ERR_INVALID, "device id %d out of range (visible: %d)", device_ids[i], n_visible);
+    hac_index *idx = new hac_index();
+    idx->d = d;
+    for (int i = 0; i < n_dev; ++i) {
+        DeviceIndex *s = new DeviceIndex();
+        int rc = s->init(d, device_ids[i]);
+        if (rc != HAC_OK) {
+            s->destroy();
+            delete s;
+            hac_index_destroy(idx);
+            return rc;
+        }
+        idx->shards.push_back(s);
+    }
+    *out = idx;
+    return HAC_OK;
+}
+
+void hac_index_destroy(hac_index *idx) {
+    if (!idx) return;
+    if (!idx->shards.empty()) {
+        DeviceGuard g(idx->shards[0]->device);
+        idx->ws_lists.release();
+        idx->ws_out.release();
+    }
+    for (auto *s : idx->shards) {
+        s->destroy();
+        delete s;
+    }
+    delete idx;
+}
+
+int hac_index_add(hac_index *idx, const float *x, int64_t n) {
+    if (!idx) return fail(HAC_ERR_INVALID, "null index");
+    if (n < 0 || (n > 0 && !x)) return fail(HAC_ERR_INVALID, "add: bad arguments");
+    if (n == 0) return HAC_OK;
+    const int S = (int)idx->shards.size();
+    // faiss IndexShards(successive_ids): rows of one add() are split contiguously across devices
+    int64_t off = 0;
+    for (int s = 0; s < S; ++s) {
+        const int64_t m = n / S + (s < n % S ? 1 : 0);
+        if (m) HAC_TRY(idx->shards[s]->add_host_rows(x + (size_t)off * idx->d, m));
+        off += m;
+    }
+    idx->ntotal += n;
+    return HAC_OK;
+}
+
+int hac_index_add_device(hac_index *idx, const float *x_dev, int64_t n, void *hip_stream) {
+    if (!idx) return fail(HAC_ERR_INVALID, "null index");
+    if (idx->shards.size() != 1) return fail(HAC_ERR_UNSUPPORTED, "add_device needs a single-device index");
+    if (n < 0 || (n > 0 && !x_dev)) return fail(HAC_ERR_INVALID, "add_device: bad arguments");
+    if (n == 0) return HAC_OK;
+    DeviceIndex *s = idx->shards[0];
+    DeviceGuard g(s->device);
+    HAC_TRY(s->add_device_rows(x_dev, n, (hipStream_t)hip_stream));
+    idx->ntotal += n;
+    return HAC_OK;
+}
+
+int hac_index_reset(hac_index *idx) {
+    if (!idx) return fail(HAC_ERR_INVALID, "null index");
+    for (auto *s : idx->shards) HAC_TRY(s->reset());
+    idx->ntotal = 0;
+    return HAC_OK;
+}
+
+int64_t hac_index_ntotal(const hac_index *idx) { return idx ? idx->ntotal : -1; }
+
+int hac_index_search_keys_device(hac_index *idx, const float *q_dev, int64_t nq, int k, uint64_t *keys_dev,
+                                 uint32_t pos_base, void *hip_stream) {
+    if (!idx) return fail(HAC_ERR_INVALID, "null index");
+    if (idx->shards.size() != 1) return fail(HAC_ERR_UNSUPPORTED, "search_keys_device needs a single-device index");
+    HAC_TRY(check_k(k));
+    if (nq < 0 || (nq > 0 && (!q_dev || !keys_dev))) return fail(HAC_ERR_INVALID, "search: bad arguments");
+    DeviceIndex *s = idx->shards[0];
+    DeviceGuard g(s->device);
+    return s->search_keys(q_dev, nq, k, (u64 *)keys_dev, pos_base, (hipStream_t)hip_stream);
+}
+
+int hac_keys_to_results_device(int device, const uint64_t *keys_dev, int64_t n_keys, const int64_t *id_map_dev,
+                               float *D_dev, int64_t *I_dev, void *hip_stream) {
+    if (n_keys < 0 || (n_keys > 0 && (!keys_dev || !D_dev || !I_dev))) return fail(HAC_ERR_INVALID, "keys_to_results: bad arguments");
+    if (n_keys == 0) return HAC_OK;
+    DeviceGuard g(device);
+    if (!g.ok) return fail(HAC_ERR_HIP, "cannot select HIP device %d", device);
+    keys_to_results_kernel<<<dim3((unsigned)((n_keys + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream>>>(
+        (const u64 *)keys_dev, (long)n_keys, (const long long *)id_map_dev, D_dev, (long long *)I_dev);
+    HAC_HIP(hipGetLastError());
+    return HAC_OK;
+}
+
+int hac_merge_keys_device(int device, const uint64_t *lists_dev, int n_lists, int64_t nq, int k, uint64_t *out_dev,
+                          void *hip_stream) {
+    HAC_TRY(check_k(k));
+    if (n_lists < 1 || nq < 0 || (nq > 0 && (!lists_dev || !out_dev))) return fail(HAC_ERR_INVALID, "merge: bad arguments");
+    if (nq == 0) return HAC_OK;
+    DeviceGuard g(device);
+    if (!g.ok) return fail(HAC_ERR_HIP, "cannot select HIP device %d", device);
+    int Cm;
+    size_t lds;
+    merge_plan_lds(k, Cm, lds);
+    static bool attr_done[64] = {false};
+    if (device >= 0 && device < 64 && !attr_done[device]) {
+        HAC_HIP(hipFuncSetAttribute((const void *)merge_keys_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * 1024)));
+        attr_done[device] = true;
+    }
+    merge_keys_kernel<<<dim3((unsigned)nq), dim3(MERGE_THREADS), lds, (hipStream_t)hip_stream>>>(
+        (const u64 *)lists_dev, n_lists, (size_t)nq * k, (size_t)k, k, Cm, (u64 *)out_dev, nullptr);
+    HAC_HIP(hipGetLastError());
+    return HAC_OK;
+}
+
+int hac_index_search_device(hac_index *idx, const float *q_dev, int64_t nq, int k, float *D_dev, int64_t *I_dev,
+                            const int64_t *id_map_dev, void *hip_stream) {
+    if (!idx) return fail(HAC_ERR_INVALID, "null index");
+    if (idx->shards.size() != 1) return fail(HAC_ERR_UNSUPPORTED, "search_device needs a single-device index");
+    HAC_TRY(check_k(k));
+    if (nq < 0 || (nq > 0 && (!q_dev || !D_dev || !I_dev))) return fail(HAC_ERR_INVALID, "search: bad arguments");
+    if (nq == 0) return HAC_OK;
+    DeviceIndex *s = idx->shards[0];
+    DeviceGuard g(s->device);
+    HAC_TRY(s->ws_keys.reserve((size_t)nq * k * 8));
+    HAC_TRY(s->search_keys(q_dev, nq, k, (u64 *)s->ws_keys.p, 0u, (hipStream_t)hip_stream));
+    return hac_keys_to_results_device(s->device, (const uint64_t *)s->ws_keys.p, nq * k, id_map_dev, D_dev, I_dev, hip_stream);
+}
+
+int hac_index_search(hac_index *idx, const float *q, int64_t nq, int k, float *D, int64_t *I) {
+    if (!idx) return fail(HAC_ERR_INVALID, "null index");
+    HAC_TRY(check_k(k));
+    if (nq < 0 || (nq > 0 && (!q || !D || !I))) return fail(HAC_ERR_INVALID, "search: bad arguments");
+    if (nq == 0) return HAC_OK;
+    const int S = (int)idx->shards.size();
+    const size_t qbytes = (size_t)nq * idx->d * 4;
+    // each shard searches its rows; positions are global (shard base + local row)
+    DeviceIndex *s0 = idx->shards[0];
+    {
+        DeviceGuard g0(s0->device);
+        HAC_TRY(idx->ws_lists.reserve((size_t)S * nq * k * 8));
+        HAC_TRY(idx->ws_out.reserve((size_t)nq * k * 8));
+    }
+    int64_t base = 0;
+    for (int si = 0; si < S; ++si) {
+        DeviceIndex *s = idx->shards[si];
+        DeviceGuard g(s->device);
+        HAC_TRY(s->ws_q.reserve(qbytes));
+        HAC_TRY(s->ws_keys.reserve((size_t)nq * k * 8));
+        HAC_TRY(s->pin_reserve(std::max(qbytes, (size_t)nq * k * 12)));
+        HAC_HIP(hipStreamSynchronize(s->stream));
+        std::memcpy(s->h_pin, q, qbytes);
+        HAC_HIP(hipMemcpyAsync(s->ws_q.p, s->h_pin, qbytes, hipMemcpyHostToDevice, s->stream));
+        HAC_TRY(s->search_keys((const float *)s->ws_q.p, nq, k, (u64 *)s->ws_keys.p, (u32)base, s->stream));
+        base += s->ntotal;
+    }
+    DeviceGuard g0(s0->device);
+    const uint64_t *final_keys = (const uint64_t *)s0->ws_keys.p;
+    if (S > 1) {
+        // gather the per-shard key slabs on shard 0's stream (never the null stream: the index
+        // streams are non-blocking, a legacy-stream D2D copy would not be ordered with them)
+        for (int si = 0; si < S; ++si) {
+            DeviceIndex *s = idx->shards[si];
+            if (si) HAC_HIP(hipStreamSynchronize(s->stream));
+            HAC_HIP(hipMemcpyAsync((char *)idx->ws_lists.p + (size_t)si * nq * k * 8, s->ws_keys.p, (size_t)nq * k * 8,
+                                   hipMemcpyDeviceToDevice, s0->stream));
+        }
+        HAC_TRY(hac_merge_keys_device(s0->device, (const uint64_t *)idx->ws_lists.p, S, nq, k, (uint64_t *)idx->ws_out.p, s0->stream));
+        final_keys = (const uint64_t *)idx->ws_out.p;
+    }
+    HAC_TRY(s0->ws_D.reserve((size_t)nq * k * 4));
+    HAC_TRY(s0->ws_I.reserve((size_t)nq * k * 8));
+    HAC_TRY(hac_keys_to_results_device(s0->device, final_keys, nq * k, nullptr, (float *)s0->ws_D.p, (int64_t *)s0->ws_I.p, s0->stream));
+    char *hp = (char *)s0->h_pin;
+    HAC_HIP(hipMemcpyAsync(hp, s0->ws_I.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s0->stream));
+    HAC_HIP(hipMemcpyAsync(hp + (size_t)nq * k * 8, s0->ws_D.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s0->stream));
+    HAC_HIP(hipStreamSynchronize(s0->stream));
+    std::memcpy(I, hp, (size_t)nq * k * 8);
+    std::memcpy(D, hp + (size_t)nq * k * 8, (size_t)nq * k * 4);
+    return HAC_OK;
+}
+
+int hac_index_set_profiling(hac_index *idx, int enable) {
+    if (!idx) return fail(HAC_ERR_INVALID, "null index");
+    for (auto *s : idx->shards) s->profiling = enable != 0;
+    return HAC_OK;
+}
+
+int hac_index_last_scan_ms(hac_index *idx, float *ms_out) {
+    if (!idx || !ms_out) return fail(HAC_ERR_INVALID, "bad arguments");
+    DeviceIndex *s = idx->shards[0];
+    if (!s->ev_valid) return fail(HAC_ERR_INVALID, "no profiled search yet (call hac_index_set_profiling first)");
+    DeviceGuard g(s->device);
+    HAC_HIP(hipEventSynchronize(s->ev1));
+    HAC_HIP(hipEventElapsedTime(ms_out, s->ev0, s->ev1));
+    return HAC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+/*
+ * haconvdr.h — C ABI of the MI355X-native dense-retrieval hot path for HAConvDR.
+ *
+ * Drop-in boundary.  The reference has no FFI; its seams are two
+ * duck-typed Python objects.  Each entry point below cites the reference call
+ * site it replaces (paths are into the upstream repo fengranMark/HAConvDR):
+ *
+ *   Index   = the object returned by build_faiss_index()
+ *             src/test_HAConvDR_topiocqa.py:39-71 (faiss.IndexFlatIP(768) :52,
+ *             sharded over GPUs :55-66) and used by search_one_by_one_with_faiss()
+ *             :74-162 through .add (:98) / .search (:102) / .reset (:122).
+ *   Encoder = model(input_ids, attention_mask) -> float32 [B,768]
+ *             src/models.py:39-64 (ANCE.forward/query_emb), called at
+ *             src/test_HAConvDR_topiocqa.py:211 and gen_doc_embeddings.py:110.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types; every function
+ * returns 0 on success or a non-zero hac_status, never throws; the message of the
+ * last failure on the calling thread is hac_last_error().  A handle is not
+ * re-entrant; distinct handles may be used from distinct threads.  "_device"
+ * variants take HIP device pointers and a hipStream_t (as void*), enqueue work on
+ * that stream and return without synchronising; host variants are synchronous
+ * like the faiss calls they replace.  There is NO CPU fallback: with no HIP
+ * device every call fails with HAC_ERR_HIP.
+ *
+ * Canonical semantics (shared with oracle/flat_ip_oracle.c): score(q, x) is the
+ * k-ordered fp32 fma chain acc = fmaf(x[k], q[k], acc), k = 0..d-1 (what the
+ * gfx950 fp32 MFMA computes natively); results are ordered by (score descending,
+ * row ascending); NaN scores are never returned; short result lists are padded
+ * with D = -FLT_MAX, I = -1 (faiss's convention).
+ */
+#ifndef HACONVDR_H
+#define HACONVDR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    HAC_OK = 0,
+    HAC_ERR_INVALID = 1,   /* bad argument (null handle, d not a multiple of 32, k out of range, ...) */
+    HAC_ERR_HIP = 2,       /* a HIP runtime call failed / no device */
+    HAC_ERR_OOM = 3,       /* device or pinned-host allocation failed */
+    HAC_ERR_UNSUPPORTED = 4
+} hac_status;
+
+#define HAC_MAX_K 2048      /* faiss-gpu 1.7.2 has the same top-k ceiling */
+#define HAC_MAX_D 1024
+
+/* ------------------------------------------------------------------ errors */
+/* Message of the last failing call on this thread ("" if none).  Never NULL. */
+const char *hac_last_error(void);
+/* Library version string, e.g. "haconvdr-amd 0.1.0 (gfx950)". */
+const char *hac_version(void);
+
+/* ------------------------------------------------------------------- index */
+typedef struct hac_index hac_index;
+
+/* faiss.IndexFlatIP(d) [+ index_cpu_to_gpu_multiple(shard=True)]:
+ * src/test_HAConvDR_topiocqa.py:52,55-66.  d must be a multiple of 32, <= HAC_MAX_D
+ * (the reference fixes d = 768).  device_ids[0..n_dev) are HIP ordinals; with
+ * n_dev > 1 the rows of every add() are split contiguously across the devices and
+ * search() merges the per-device top-k (faiss IndexShards semantics, one host
+ * thread).  The scalable path is one process per GPU (haconvdr_amd.sharded). */
+int hac_index_create(int d, const int *device_ids, int n_dev, hac_index **out);
+void hac_index_destroy(hac_index *idx);
+
+/* index.add(passage_embedding) — src/test_HAConvDR_topiocqa.py:98.
+ * x: host pointer, float32 row-major [n, d]; copied (and re-tiled for the MFMA
+ * scan) before return — the caller may free it (the reference does, :123). */
+int hac_index_add(hac_index *idx, const float *x, int64_t n);
+/* Same, x already in device memory of the index's (single) device. */
+int hac_index_add_device(hac_index *idx, const float *x_dev, int64_t n, void *hip_stream);
+
+/* D, I = index.search(query_embeddings, topN) — src/test_HAConvDR_topiocqa.py:102.
+ * q: host float32 [nq, d]; D: host float32 [nq, k]; I: host int64 [nq, k]
+ * (rows numbered by insertion order since the last reset).  Synchronous. */
+int hac_index_search(hac_index *idx, const float *q, int64_t nq, int k, float *D, int64_t *I);
+/* Device/stream variant (single-device index).  id_map_dev (optional, int64
+ * [ntotal]) maps row -> external id, fusing `passage_embedding2id[I]` (:110). */
+int hac_index_search_device(hac_index *idx, const float *q_dev, int64_t nq, int k, float *D_dev,
+                            int64_t *I_dev, const int64_t *id_map_dev, void *hip_stream);
+/* Top-k as packed 64-bit keys, [nq, k] sorted descending, 0 = empty slot:
+ *   key = (orderable(score) << 32) | (0xFFFFFFFF - (pos_base + row)).
+ * This is the unit exchanged between corpus shards (one all-gather of keys). */
+int hac_index_search_keys_device(hac_index *idx, const float *q_dev, int64_t nq, int k,
+                                 uint64_t *keys_dev, uint32_t pos_base, void *hip_stream);
+
+/* index.reset() — src/test_HAConvDR_topiocqa.py:122.  Keeps allocations for reuse. */
+int hac_index_reset(hac_index *idx);
+/* index.ntotal */
+int64_t hac_index_ntotal(const hac_index *idx);
+
+/* Profiling aid for bench.py: when enabled, the main scan kernel of every search
+ * is bracketed by hipEvents on the launch stream; hac_index_last_scan_ms() waits
+ * for them and returns the kernel time of the most recent search (ms). */
+int hac_index_set_profiling(hac_index *idx, int enable);
+int hac_index_last_scan_ms(hac_index *idx, float *ms_out);
+
+/* ------------------------------------------------------- top-k list merging */
+/* K9: merge L per-block / per-shard key lists into one.  lists_dev: uint64
+ * [L, nq, k] (each [nq,k] slab sorted descending, 0 = empty); out_dev: [nq, k].
+ * Equals the reference's sequential `>=` block merge (:131-149) when slabs are in
+ * block order and positions increase with the block index. */
+int hac_merge_keys_device(int device, const uint64_t *lists_dev, int n_lists, int64_t nq, int k,
+                          uint64_t *out_dev, void *hip_stream);
+/* keys -> (D float32, I int64); id_map_dev optional (position -> external id). */
+int hac_keys_to_results_device(int device, const uint64_t *keys_dev, int64_t n_keys,
+                               const int64_t *id_map_dev, float *D_dev, int64_t *I_dev,
+                               void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HACONVDR_H */

@@ -109,6 +109,7 @@ CASES = [
     ("grid_3blk_k100", "grid", 1200, 5, 100, 3, 3),
     ("dup_rows_across_blocks", "dup", 400, 4, 10, 2, 2),   # identical rows in two blocks: tie rule (:138)
     ("short_block_k100", "gauss", 150, 3, 100, 2, 2),      # blocks shorter than topN -> -1 / -FLT_MAX padding
+    ("tiny_total_k100", "gauss", 60, 2, 100, 2, 2),        # fewer than topN rows in total: pads reach the output
 ]
 
 

@@ -1,0 +1,282 @@
+"""GPU parity tests of the exact-IP search path, THROUGH THE C ABI (ctypes ->
+libhaconvdr.so).  Bar: ids and scores bit-exact against the oracle and against the
+golden vectors produced by the reference's own merge code."""
+import glob
+import os
+import pickle
+import argparse
+
+import numpy as np
+import pytest
+
+from tests.golden import cases
+
+pytestmark = pytest.mark.gpu
+
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "search_*.npz")))
+FMAX = np.finfo(np.float32).max
+
+
+@pytest.fixture(scope="module")
+def index():
+    from haconvdr_amd.index import FlatIPIndex
+    idx = FlatIPIndex(768, devices=(0,))
+    yield idx
+    idx.reset()
+
+
+def assert_same(D, I, oD, oI):
+    np.testing.assert_array_equal(I, oI)
+    np.testing.assert_array_equal(D, oD)
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[7:-4] for p in GOLD])
+def test_three_call_protocol_vs_golden(path, index, oracle):
+    """add / search / reset per block exactly as search_one_by_one_with_faiss drives them
+    (:98,:102,:122); per-block results must equal the oracle's, and the python-side merge of
+    them (the oracle's restated merge) must equal the reference's golden output."""
+    g = np.load(path)
+    x, q, ids = cases.search_case_inputs(str(g["kind"]), int(g["seed"]), int(g["n"]), int(g["nq"]))
+    topN, bounds = int(g["topN"]), g["bounds"]
+    index.reset()
+    per_block = []
+    for b in range(int(g["nblocks"])):
+        xb = x[bounds[b]:bounds[b + 1]]
+        index.add(xb)
+        assert index.ntotal == len(xb)
+        D, I = index.search(q, topN)
+        assert D.dtype == np.float32 and I.dtype == np.int64 and D.shape == (len(q), topN)
+        oD, oI = oracle.flat_ip_search(xb, q, topN)
+        assert_same(D, I, oD, oI)
+        per_block.append((D, I))
+        index.reset()
+        assert index.ntotal == 0
+
+    class Replay:  # feeds the GPU's per-block results through the oracle's restated merge
+        def __init__(self):
+            self.i = -1
+        def add(self, x):
+            self.i += 1
+        def search(self, q, k):
+            return per_block[self.i]
+        def reset(self):
+            pass
+    import oracle.oracle as om
+    saved = om.OracleIndex
+    om.OracleIndex = lambda d: Replay()
+    try:
+        mD, mI = om.search_one_by_one([(x[bounds[b]:bounds[b + 1]], ids[bounds[b]:bounds[b + 1]])
+                                       for b in range(int(g["nblocks"]))], q, topN)
+    finally:
+        om.OracleIndex = saved
+    np.testing.assert_array_equal(mI, g["ref_I"][:, :topN])
+    np.testing.assert_array_equal(mD, g["ref_D"][:, :topN])
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[7:-4] for p in GOLD])
+def test_search_one_by_one_dropin_vs_golden(path, index, tmp_path):
+    """The product's search_one_by_one (resident blocks, one on-device top-k, fused id remap)
+    on the reference's on-disk block format must reproduce the reference's output."""
+    from haconvdr_amd.search import search_one_by_one
+    g = np.load(path)
+    x, q, ids = cases.search_case_inputs(str(g["kind"]), int(g["seed"]), int(g["n"]), int(g["nq"]))
+    topN, bounds = int(g["topN"]), g["bounds"]
+    for b in range(int(g["nblocks"])):
+        with open(tmp_path / f"passage_emb_block_{b}.pb", "wb") as f:
+            pickle.dump(x[bounds[b]:bounds[b + 1]], f, protocol=4)
+        with open(tmp_path / f"passage_embid_block_{b}.pb", "wb") as f:
+            pickle.dump(ids[bounds[b]:bounds[b + 1]], f, protocol=4)
+    name = os.path.basename(path)
+    block_num = 5 if "missing" in name else int(g["nblocks"])
+    mD, mI = search_one_by_one(argparse.Namespace(passage_block_num=block_num), str(tmp_path), index, q, topN)
+    assert mD.dtype == np.float64 and mI.dtype == np.int64 and mD.shape == (len(q), topN)
+    np.testing.assert_array_equal(mI, g["ref_I"][:, :topN])
+    np.testing.assert_array_equal(mD, g["ref_D"][:, :topN])
+
+
+@pytest.mark.parametrize("n,nq,k", [(1, 1, 1), (63, 3, 10), (64, 16, 64), (65, 17, 100), (1000, 33, 100),
+                                    (5000, 4, 1000), (3000, 2, 2048), (20000, 40, 10)])
+def test_parity_random(n, nq, k, index, oracle):
+    x, q, _ = cases.search_case_inputs("gauss", 1000 + n + nq, n, nq)
+    index.reset()
+    index.add(x)
+    D, I = index.search(q, k)
+    assert_same(D, I, *oracle.flat_ip_search(x, q, k))
+
+
+def test_cfg1_10k_100q_top10(index, oracle):
+    """BASELINE.json configs[0]: 10k x 768 passages, 100 queries, top-10."""
+    x, q, _ = cases.search_case_inputs("gauss", 0xC0FFEE, 10000, 100)
+    index.reset()
+    index.add(x)
+    D, I = index.search(q, 10)
+    assert_same(D, I, *oracle.flat_ip_search(x, q, 10))
+
+
+def test_many_adds_segments_and_reuse(index, oracle):
+    x, q, _ = cases.search_case_inputs("gauss", 4242, 9000, 9)
+    index.reset()
+    cuts = [0, 1, 2, 65, 129, 1000, 1001, 4097, 9000]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        index.add(x[a:b])
+    assert index.ntotal == 9000
+    assert_same(*index.search(q, 100), *oracle.flat_ip_search(x, q, 100))
+    index.reset()                       # allocation is kept and refilled
+    index.add(x[:700])
+    assert_same(*index.search(q, 100), *oracle.flat_ip_search(x[:700], q, 100))
+    for i in range(80):                 # more segments than the descriptor table: forces consolidation
+        index.add(x[700 + i * 64: 700 + (i + 1) * 64 - (i % 3)])
+    rows = np.concatenate([x[:700]] + [x[700 + i * 64: 700 + (i + 1) * 64 - (i % 3)] for i in range(80)])
+    assert index.ntotal == len(rows)
+    assert_same(*index.search(q, 50), *oracle.flat_ip_search(rows, q, 50))
+
+
+def test_ties_row_ascending(index, oracle):
+    x = np.zeros((5000, 768), np.float32)
+    x[:, 0] = 1.0
+    x[100:110, 1] = 1.0
+    x[4000:4010, 1] = 1.0
+    q = np.zeros((3, 768), np.float32)
+    q[0, 0], q[0, 1] = 1.0, 0.5
+    q[2, 0] = -1.0
+    index.reset()
+    index.add(x)
+    D, I = index.search(q, 120)
+    oD, oI = oracle.flat_ip_search(x, q, 120)
+    assert_same(D, I, oD, oI)
+    assert list(I[0, :20]) == list(range(100, 110)) + list(range(4000, 4010))
+    assert list(I[1]) == list(range(120))            # all-zero query: every score ties at 0
+
+
+def test_nan_rows_and_negative_zero(index, oracle):
+    x, q, _ = cases.search_case_inputs("gauss", 99, 700, 5)
+    x[13, 5] = np.nan
+    x[640, 700] = np.nan
+    x[77] = -0.0
+    x[78] = 0.0
+    index.reset()
+    index.add(x)
+    D, I = index.search(q, 700)
+    oD, oI = oracle.flat_ip_search(x, q, 700)
+    assert_same(D, I, oD, oI)
+    assert np.all(I[:, -2:] == -1) and np.all(D[:, -2:] == -FMAX)
+    assert 13 not in I and 640 not in I
+
+
+def test_short_and_empty(index):
+    x, q, _ = cases.search_case_inputs("gauss", 5, 7, 2)
+    index.reset()
+    D, I = index.search(q, 10)
+    assert np.all(I == -1) and np.all(D == -FMAX)
+    index.add(x)
+    D, I = index.search(q, 10)
+    assert np.all(I[:, 7:] == -1) and np.all(D[:, 7:] == -FMAX) and np.all(I[:, :7] >= 0)
+    D, I = index.search(q[:0], 10)
+    assert D.shape == (0, 10)
+
+
+def test_errors_are_loud(index):
+    from haconvdr_amd._lib import HacError
+    from haconvdr_amd.index import FlatIPIndex
+    q = np.zeros((1, 768), np.float32)
+    with pytest.raises(HacError):
+        index.search(q, 0)
+    with pytest.raises(HacError):
+        index.search(q, 4096)
+    with pytest.raises(ValueError):
+        index.add(np.zeros((3, 100), np.float32))
+    with pytest.raises(HacError):
+        FlatIPIndex(100)
+    with pytest.raises(HacError):
+        FlatIPIndex(768, devices=(99,))
+
+
+def test_in_process_shards_same_device(oracle):
+    """faiss shard=True semantics (:55-66) with two shards on the one GPU of the test box:
+    rows of every add() are split contiguously, per-shard top-k merged on device."""
+    from haconvdr_amd.index import FlatIPIndex
+    x, q, _ = cases.search_case_inputs("dup", 31337, 3000, 6)
+    idx = FlatIPIndex(768, devices=(0, 0, 0))
+    idx.add(x[:1000])
+    idx.add(x[1000:])
+    assert idx.ntotal == 3000
+    D, I = idx.search(q, 100)
+    # global row numbering of the sharded index: shard s holds [its part of add 1, its part of add 2]
+    parts = [[], [], []]
+    for lo, hi in ((0, 1000), (1000, 3000)):
+        n = hi - lo
+        off = lo
+        for s in range(3):
+            m = n // 3 + (1 if s < n % 3 else 0)
+            parts[s].append(np.arange(off, off + m))
+            off += m
+    order = np.concatenate([np.concatenate(p) for p in parts])
+    oD, oI = oracle.flat_ip_search(x[order], q, 100)
+    assert_same(D, I, oD, oI)
+
+
+def test_merge_keys_matches_reference_merge(oracle):
+    """hac_merge_keys_device over per-block key lists == the reference's sequential `>=` merge."""
+    import torch
+    from haconvdr_amd.index import FlatIPIndex, merge_keys, keys_to_results
+    x, q, ids = cases.search_case_inputs("dup", 777, 2000, 5)
+    idx = FlatIPIndex(768)
+    qd = torch.from_numpy(q).cuda()
+    lists, base = [], 0
+    bounds = [0, 500, 1000, 1500, 2000]
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        idx.reset()
+        idx.add(x[a:b])
+        lists.append(idx.search_keys_tensor(qd, 100, pos_base=a))
+    merged = merge_keys(torch.stack(lists))
+    D, I = keys_to_results(merged, id_map=torch.from_numpy(ids).cuda())
+    mD, mI = oracle.search_one_by_one([(x[a:b], ids[a:b]) for a, b in zip(bounds[:-1], bounds[1:])], q, 100)
+    np.testing.assert_array_equal(I.cpu().numpy(), mI)
+    np.testing.assert_array_equal(D.cpu().numpy().astype(np.float64), mD)
+
+
+def test_full_size_cfg2_properties(oracle):
+    """BASELINE.json configs[1] at full size (1M x 768, 1000 queries, top-100): bit-exact vs the
+    oracle on a query subset, plus size-independent properties on all queries."""
+    import torch
+    from haconvdr_amd.index import FlatIPIndex
+    N, NQ, K = 1_000_000, 1000, 100
+    gen = torch.Generator(device="cuda").manual_seed(0xC0FFEE)
+    idx = FlatIPIndex(768)
+    xs = []
+    for i in range(0, N, 250_000):
+        xb = torch.randn((250_000, 768), generator=gen, device="cuda")
+        xb = (xb - xb.mean(1, keepdim=True)) / xb.std(1, unbiased=False, keepdim=True)
+        idx.add_tensor(xb)
+        xs.append(xb)
+    torch.cuda.synchronize()
+    q = torch.randn((NQ, 768), generator=gen, device="cuda")
+    q = (q - q.mean(1, keepdim=True)) / q.std(1, unbiased=False, keepdim=True)
+    D, I = idx.search_tensor(q, K)
+    torch.cuda.synchronize()
+    # (a) sorted, in range, no duplicates
+    assert bool((D[:, :-1] >= D[:, 1:]).all()) and int(I.min()) >= 0 and int(I.max()) < N
+    assert all(len(set(r)) == K for r in I[:50].cpu().tolist())
+    # (b) split invariance: top-k of the union == merge of the halves' top-k
+    h1, h2 = FlatIPIndex(768), FlatIPIndex(768)
+    for xb in xs[:2]:
+        h1.add_tensor(xb)
+    for xb in xs[2:]:
+        h2.add_tensor(xb)
+    from haconvdr_amd.index import merge_keys, keys_to_results
+    k1 = h1.search_keys_tensor(q, K, pos_base=0)
+    k2 = h2.search_keys_tensor(q, K, pos_base=500_000)
+    D2, I2 = keys_to_results(merge_keys(torch.stack([k1, k2])))
+    assert torch.equal(I2, I) and torch.equal(D2, D)
+    del h1, h2
+    # (c) every returned score is the exact fp32 fma-chain score of its row, and nothing outside beats the k-th
+    xall = torch.cat(xs)
+    approx = q[:64] @ xall.T
+    kth = D[:64, -1:]
+    assert int((approx > kth + 1e-3).sum(1).max()) <= K
+    # (d) bit-exact vs the oracle on 8 queries
+    xh = xall.cpu().numpy()
+    sel = [0, 1, 2, 3, 500, 997, 998, 999]
+    oD, oI = oracle.flat_ip_search(xh, q[sel].cpu().numpy(), K)
+    np.testing.assert_array_equal(I[sel].cpu().numpy(), oI)
+    np.testing.assert_array_equal(D[sel].cpu().numpy(), oD)
