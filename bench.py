@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Headline benchmark: queries/sec of exact inner-product top-100 search over a 768-d
+passage-embedding corpus (BASELINE.json configs[1]: 1M x 768 corpus, 1000 queries,
+pre-encoded embeddings resident in HBM, one MI355X).
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+A step = one search of the whole query batch over the resident corpus.  With N>1 the 1M-row
+corpus is split into N contiguous shards (strong scaling: total work fixed), every rank
+scans its shard for all queries, one RCCL all-gather of the packed per-shard top-k keys and
+an on-device merge finish the step on every rank.
+
+Rank 0 prints ONE JSON line; see DESIGN.md §measurement for the roofline arithmetic.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+D_EMB = 768
+PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+PEAK_F32_MFMA_TF = 157.3    # fp32-input MFMA dense peak
+
+
+def gen_rows(seed, n, device):
+    """Row-standardised Gaussian rows (||x|| = sqrt(768)), the shape of the ANCE head's output."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    x = torch.randn((n, D_EMB), generator=g, device=device, dtype=torch.float32)
+    return (x - x.mean(1, keepdim=True)) / x.std(1, unbiased=False, keepdim=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=1_000_000, help="total corpus rows (configs[1]: 1M)")
+    ap.add_argument("--nq", type=int, default=1000)
+    ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from haconvdr_amd.index import FlatIPIndex, keys_to_results
+    from haconvdr_amd.sharded import ShardedSearcher, shard_range
+
+    # ---- synthetic data, generated in HBM (seeds per 125k-row chunk: same corpus for every N)
+    lo, hi = shard_range(args.rows, rank, world)
+    index = FlatIPIndex(D_EMB, devices=(local_rank,))
+    CH = 125_000
+    keep_for_cpu = []
+    for c0 in range(0, args.rows, CH):
+        a, b = max(lo, c0), min(hi, c0 + CH)
+        if a >= b:
+            continue
+        xb = gen_rows(0xC0FFEE + c0 // CH, min(CH, args.rows - c0), dev)[a - c0:b - c0].contiguous()
+        index.add_tensor(xb)
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            keep_for_cpu.append(xb.cpu().numpy())
+        del xb
+    q = gen_rows(0xBEEF, args.nq, dev)
+    torch.cuda.synchronize()
+    searcher = ShardedSearcher(index, shard_base=lo)
+
+    def step():
+        return searcher.search(q, args.k)
+
+    for _ in range(args.warmup):
+        step()
+    index.set_profiling(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        D, I = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    scan_ms = index.profile_drain()
+    index.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    ms_per_step = dt / args.steps * 1e3
+    value = args.nq * args.steps / dt
+
+    # ---- roofline of the dominant kernel (scan16_kernel), algorithmic figures per launch
+    n_local = hi - lo
+    scan_avg_ms = float(np.mean(scan_ms)) if scan_ms else float("nan")
+    alg_bytes = n_local * D_EMB * 4 + args.nq * D_EMB * 4 + args.nq * args.k * 12
+    alg_flops = 2.0 * args.nq * n_local * D_EMB
+    hbm_gbs = alg_bytes / (scan_avg_ms * 1e-3) / 1e9
+    mfma_tf = alg_flops / (scan_avg_ms * 1e-3) / 1e12
+    # fp32 arithmetic intensity nq/2 flop/B against the ridge 157.3 TF / 8 TB/s = 19.7 flop/B
+    mfma_bound = (alg_flops / alg_bytes) > (PEAK_F32_MFMA_TF * 1e12) / (PEAK_HBM_GBS * 1e9)
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(pmc_path) and world == 1:
+        try:
+            pmc = json.load(open(pmc_path))
+            if pmc.get("rows") == args.rows and pmc.get("nq") == args.nq:
+                traffic = pmc.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    if mfma_bound:
+        roofline = {"kernel": "scan16_kernel", "bound": "mfma", "achieved": round(mfma_tf, 2), "peak": PEAK_F32_MFMA_TF,
+                    "unit": "TFLOP/s", "frac": round(mfma_tf / PEAK_F32_MFMA_TF, 4), "traffic": traffic,
+                    "kernel_ms": round(scan_avg_ms, 4), "hbm_GBps_same_kernel": round(hbm_gbs, 1),
+                    "hbm_frac_same_kernel": round(hbm_gbs / PEAK_HBM_GBS, 4)}
+    else:
+        roofline = {"kernel": "scan16_kernel", "bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": PEAK_HBM_GBS,
+                    "unit": "GB/s", "frac": round(hbm_gbs / PEAK_HBM_GBS, 4), "traffic": traffic,
+                    "kernel_ms": round(scan_avg_ms, 4), "mfma_TFLOPs_same_kernel": round(mfma_tf, 2)}
+
+    # ---- the HBM-bound regime of the same kernel (<= 16 queries per corpus pass), N=1 only
+    hbm_regime = None
+    if world == 1:
+        q16 = q[:16].contiguous()
+        for _ in range(3):
+            index.search_tensor(q16, args.k)
+        index.set_profiling(True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        reps = 20
+        for _ in range(reps):
+            index.search_tensor(q16, args.k)
+        torch.cuda.synchronize()
+        dt16 = (time.perf_counter() - t1) / reps
+        ms16 = float(np.mean(index.profile_drain()))
+        index.set_profiling(False)
+        b16 = n_local * D_EMB * 4 + 16 * D_EMB * 4 + 16 * args.k * 12
+        hbm_regime = {"nq": 16, "kernel_ms": round(ms16, 4), "search_ms": round(dt16 * 1e3, 4),
+                      "achieved_GBps": round(b16 / (ms16 * 1e-3) / 1e9, 1),
+                      "frac_of_8TBps": round(b16 / (ms16 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                      "queries_per_sec": round(16 / dt16, 1)}
+
+    # ---- CPU baseline: the oracle (C port, OpenMP) on the host cores, bounded sample of the same workload
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle
+        xh = np.concatenate(keep_for_cpu)
+        qh = q.cpu().numpy()
+        cores = len(os.sched_getaffinity(0))
+        os.environ["OMP_NUM_THREADS"] = str(cores)
+        nq_probe = min(args.nq, 8 * cores)
+        tp = time.perf_counter()
+        oracle.flat_ip_search(xh, qh[:nq_probe], args.k)
+        probe = time.perf_counter() - tp
+        nq_s = int(min(args.nq, max(nq_probe, (args.cpu_seconds / max(probe, 1e-3)) * nq_probe // (8 * cores) * 8 * cores)))
+        tp = time.perf_counter()
+        oD, oI = oracle.flat_ip_search(xh, qh[:nq_s], args.k)
+        tcpu = time.perf_counter() - tp
+        same = bool(np.array_equal(oI, I[:nq_s].cpu().numpy()) and np.array_equal(oD, D[:nq_s].cpu().numpy()))
+        cpu_baseline = {"value": round(nq_s / tcpu, 2), "unit": "queries/s", "cores": oracle.num_threads(), "kind": "port",
+                        "sample": f"first {nq_s} of the {args.nq} queries over the full {args.rows}x768 corpus, "
+                                  f"oracle/flat_ip_oracle.c (OpenMP, AVX2 fmaf chain), {tcpu:.1f} s",
+                        "ids_and_scores_equal_to_gpu": same}
+
+    if rank == 0:
+        out = {
+            "metric": "queries/sec (top-100 exact IP search) over N-passage 768-d corpus",
+            "value": round(value, 1), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: {args.rows}x768 fp32 corpus resident in HBM, {args.nq} queries/step, "
+                                   f"top-{args.k}, IP search only (pre-encoded embeddings)",
+                       "corpus_rows": args.rows, "queries_per_step": args.nq, "k": args.k,
+                       "parallelism": f"corpus sharded {world}-way, all-gather of packed top-k keys" if world > 1 else "single GPU"},
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+            "hbm_regime": hbm_regime,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -39,12 +39,12 @@ def _declare(L):
     L.hac_index_ntotal.argtypes = [vp]
     L.hac_index_ntotal.restype = i64
     L.hac_index_set_profiling.argtypes = [vp, ctypes.c_int]
-    L.hac_index_last_scan_ms.argtypes = [vp, c_f32p]
+    L.hac_index_profile_drain.argtypes = [vp, c_f32p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
     L.hac_merge_keys_device.argtypes = [ctypes.c_int, vp, ctypes.c_int, i64, ctypes.c_int, vp, vp]
     L.hac_keys_to_results_device.argtypes = [ctypes.c_int, vp, i64, vp, vp, vp, vp]
     for name in ("hac_index_create", "hac_index_add", "hac_index_add_device", "hac_index_search",
                  "hac_index_search_device", "hac_index_search_keys_device", "hac_index_reset",
-                 "hac_index_set_profiling", "hac_index_last_scan_ms", "hac_merge_keys_device",
+                 "hac_index_set_profiling", "hac_index_profile_drain", "hac_merge_keys_device",
                  "hac_keys_to_results_device"):
         getattr(L, name).restype = ctypes.c_int
 
@@ -53,7 +53,7 @@ def _declare(L):
 EXPORTED_SYMBOLS = (
     "hac_last_error", "hac_version", "hac_index_create", "hac_index_destroy", "hac_index_add",
     "hac_index_add_device", "hac_index_search", "hac_index_search_device", "hac_index_search_keys_device",
-    "hac_index_reset", "hac_index_ntotal", "hac_index_set_profiling", "hac_index_last_scan_ms",
+    "hac_index_reset", "hac_index_ntotal", "hac_index_set_profiling", "hac_index_profile_drain",
     "hac_merge_keys_device", "hac_keys_to_results_device",
 )
 

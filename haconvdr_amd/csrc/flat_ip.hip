@@ -412,9 +412,10 @@ struct DeviceIndex {
         return HAC_OK;
     }
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    // profiling: one hipEvent pair per search around the main scan kernel, on the launch stream
     bool profiling = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool ev_valid = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
 
     int init(int d_, int device_) {
         d = d_;
@@ -428,8 +429,6 @@ struct DeviceIndex {
         HAC_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         HAC_HIP(hipMalloc((void **)&d_segs, sizeof(SegDesc) * MAX_SEG));
         HAC_HIP(hipHostMalloc((void **)&h_segs, sizeof(SegDesc) * MAX_SEG, hipHostMallocDefault));
-        HAC_HIP(hipEventCreate(&ev0));
-        HAC_HIP(hipEventCreate(&ev1));
         for (int i = 0; i < 2; ++i) HAC_HIP(hipEventCreateWithFlags(&stage_ev[i], hipEventDisableTiming));
         static bool attr_done[64] = {false};
         if (device < 64 && !attr_done[device]) {
@@ -458,8 +457,10 @@ struct DeviceIndex {
             if (h_stage[i]) (void)hipHostFree(h_stage[i]);
             if (stage_ev[i]) (void)hipEventDestroy(stage_ev[i]);
         }
-        if (ev0) (void)hipEventDestroy(ev0);
-        if (ev1) (void)hipEventDestroy(ev1);
+        for (auto &e : ev_pool) {
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -653,12 +654,20 @@ struct DeviceIndex {
         a.partial = (u64 *)ws_partial.p;
         a.pos_base = pos_base;
         HAC_HIP(hipMemsetAsync(ws_thrglob.p, 0, (size_t)nq * 4, st));
-        if (timed) HAC_HIP(hipEventRecord(ev0, st));
+        if (timed) {
+            if (ev_used == ev_pool.size()) {
+                hipEvent_t a0, a1;
+                HAC_HIP(hipEventCreate(&a0));
+                HAC_HIP(hipEventCreate(&a1));
+                ev_pool.emplace_back(a0, a1);
+            }
+            HAC_HIP(hipEventRecord(ev_pool[ev_used].first, st));
+        }
         scan16_kernel<<<dim3((unsigned)P, (unsigned)pl.n_qtiles), dim3(SCAN_WAVES * 64), pl.lds_scan, st>>>(a);
         HAC_HIP(hipGetLastError());
         if (timed) {
-            HAC_HIP(hipEventRecord(ev1, st));
-            ev_valid = true;
+            HAC_HIP(hipEventRecord(ev_pool[ev_used].second, st));
+            ++ev_used;
         }
         return HAC_OK;
     }
@@ -933,13 +942,17 @@ int hac_index_set_profiling(hac_index *idx, int enable) {
     return HAC_OK;
 }
 
-int hac_index_last_scan_ms(hac_index *idx, float *ms_out) {
-    if (!idx || !ms_out) return fail(HAC_ERR_INVALID, "bad arguments");
+int hac_index_profile_drain(hac_index *idx, float *ms_out, int cap, int *n_out) {
+    if (!idx || !n_out || (cap > 0 && !ms_out)) return fail(HAC_ERR_INVALID, "bad arguments");
     DeviceIndex *s = idx->shards[0];
-    if (!s->ev_valid) return fail(HAC_ERR_INVALID, "no profiled search yet (call hac_index_set_profiling first)");
     DeviceGuard g(s->device);
-    HAC_HIP(hipEventSynchronize(s->ev1));
-    HAC_HIP(hipEventElapsedTime(ms_out, s->ev0, s->ev1));
+    int n = 0;
+    for (size_t i = 0; i < s->ev_used && n < cap; ++i, ++n) {
+        HAC_HIP(hipEventSynchronize(s->ev_pool[i].second));
+        HAC_HIP(hipEventElapsedTime(&ms_out[n], s->ev_pool[i].first, s->ev_pool[i].second));
+    }
+    s->ev_used = 0;
+    *n_out = n;
     return HAC_OK;
 }
 

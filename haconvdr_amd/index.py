@@ -107,10 +107,12 @@ class FlatIPIndex:
     def set_profiling(self, on=True):
         _lib.check(_lib.lib().hac_index_set_profiling(self._h, int(bool(on))))
 
-    def last_scan_ms(self):
-        ms = ctypes.c_float()
-        _lib.check(_lib.lib().hac_index_last_scan_ms(self._h, ctypes.byref(ms)))
-        return float(ms.value)
+    def profile_drain(self, cap=4096):
+        """Durations (ms) of the main scan kernel of every search since the last drain."""
+        buf = (ctypes.c_float * cap)()
+        n = ctypes.c_int()
+        _lib.check(_lib.lib().hac_index_profile_drain(self._h, buf, cap, ctypes.byref(n)))
+        return [float(buf[i]) for i in range(n.value)]
 
 
 def merge_keys(lists, stream=None):

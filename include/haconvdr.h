@@ -93,11 +93,12 @@ int hac_index_reset(hac_index *idx);
 /* index.ntotal */
 int64_t hac_index_ntotal(const hac_index *idx);
 
-/* Profiling aid for bench.py: when enabled, the main scan kernel of every search
- * is bracketed by hipEvents on the launch stream; hac_index_last_scan_ms() waits
- * for them and returns the kernel time of the most recent search (ms). */
+/* Profiling aid for bench.py: when enabled, the main scan kernel of every search is
+ * bracketed by a hipEvent pair recorded on the launch stream (no host sync).
+ * hac_index_profile_drain() waits for the recorded pairs, writes up to cap kernel
+ * durations (ms, in launch order) to ms_out, sets *n_out and clears the record. */
 int hac_index_set_profiling(hac_index *idx, int enable);
-int hac_index_last_scan_ms(hac_index *idx, float *ms_out);
+int hac_index_profile_drain(hac_index *idx, float *ms_out, int cap, int *n_out);
 
 /* ------------------------------------------------------- top-k list merging */
 /* K9: merge L per-block / per-shard key lists into one.  lists_dev: uint64
