@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -159,6 +160,7 @@ struct ScanArgs {
     const SegDesc *segs;
     int nseg;
     const float4 *q;        // [nq][K4] row-major queries
+    const float4 *qt;       // scanq only: queries re-tiled to [tile][K4][NQ] float4, zero padded
     int nq, K4, k, C, QT;   // C: candidate slots per query (pow2 >= k + 64*SCAN_WAVES); QT queries per workgroup
     long n_rows;            // valid rows in the index
     u32 g_first, g_step, n_items;  // work items i -> group g_first + i*g_step
@@ -308,6 +310,237 @@ __global__ __launch_bounds__(SCAN_WAVES * 64) void scan16_kernel(ScanArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ scan kernel, many queries
+// GEMM-shaped variant for nq > 16: one workgroup of W waves scores NQ = 32*NT queries against
+// W groups (64 rows each) per round.  A (corpus) still streams global -> VGPR in T64 chunks;
+// B (queries) is re-tiled once into [tile][d/4][NQ] float4 and staged slice by slice (16 chunks =
+// 64 k) through a double-buffered LDS image shared by all waves, so the corpus is re-read
+// nq/NQ times instead of nq/16 times.  MFMA: v_mfma_f32_32x32x1_2b_f32 (lane l <-> row l of the
+// group as A, query l&31 as B; bit-exact k-ordered fmaf chain).  Candidate buffers are only
+// C = next_pow2(k+1) slots per query; a full buffer raises an overflow flag, the owners compact
+// (sort, keep k, raise the threshold) and the waves re-offer what is still pending.
+typedef float f32x32 __attribute__((ext_vector_type(32)));
+
+__global__ void retile_queries_kernel(const float4 *__restrict__ q, int nq, int K4, int NQ, int n_tiles,
+                                      float4 *__restrict__ out) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)n_tiles * K4 * NQ;
+    if (idx >= total) return;
+    const int j = (int)(idx % NQ);
+    const long r = idx / NQ;
+    const int k4 = (int)(r % K4);
+    const int tile = (int)(r / K4);
+    const long qi = (long)tile * NQ + j;
+    out[idx] = qi < nq ? q[qi * K4 + k4] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+#define HAC_MFMA4_32(accv, av, bv)                                                   \
+    accv = __builtin_amdgcn_mfma_f32_32x32x1f32((av).x, (bv).x, accv, 0, 0, 0);      \
+    accv = __builtin_amdgcn_mfma_f32_32x32x1f32((av).y, (bv).y, accv, 0, 0, 0);      \
+    accv = __builtin_amdgcn_mfma_f32_32x32x1f32((av).z, (bv).z, accv, 0, 0, 0);      \
+    accv = __builtin_amdgcn_mfma_f32_32x32x1f32((av).w, (bv).w, accv, 0, 0, 0);
+
+template <int NT, int W>
+__global__ __launch_bounds__(W * 64) void scanq_kernel(ScanArgs a) {
+    constexpr int NQ = 32 * NT;
+    constexpr int KC = 16;                 // chunks (of 4 k) per staged query slice
+    constexpr int NTHR = W * 64;
+    constexpr int STG = KC * NQ / NTHR;    // float4 staged per thread per slice
+    static_assert(KC * NQ % NTHR == 0, "slice must divide evenly over the workgroup");
+    static_assert(KC % PF == 0, "prefetch ring must divide the slice");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K4 = a.K4;
+    const int NS = K4 / KC;
+    const int q0 = blockIdx.y * NQ;
+    const int NQr = min(NQ, a.nq - q0);
+    const int C = a.C;
+
+    float4 *qs = reinterpret_cast<float4 *>(smem);                         // [2][KC][NQ]
+    u64 *cand = reinterpret_cast<u64 *>(smem + (size_t)2 * KC * NQ * 16);  // [NQ][C]
+    u32 *cnt = reinterpret_cast<u32 *>(cand + (size_t)NQ * C);             // [NQ]
+    float *thr = reinterpret_cast<float *>(cnt + NQ);                      // [NQ]
+    u32 *ovf = reinterpret_cast<u32 *>(thr + NQ);                          // [1]
+    const float4 *qsrc = a.qt + (size_t)blockIdx.y * K4 * NQ;
+
+    for (int i = tid; i < NQ; i += NTHR) {
+        cnt[i] = 0;
+        thr[i] = i < NQr ? (a.thr_init ? a.thr_init[q0 + i] : -INFINITY) : INFINITY;  // padded queries admit nothing
+    }
+    if (tid == 0) *ovf = 0;
+#pragma unroll
+    for (int i = 0; i < STG; ++i) qs[tid + i * NTHR] = qsrc[tid + i * NTHR];
+    __syncthreads();
+
+    const int jl = lane & 31;
+    const u32 stride = gridDim.x * W;
+    const u32 nrounds = (a.n_items + stride - 1) / stride;
+    const u32 hw = (u32)(C + a.k) / 2;  // compact once a buffer is past the midpoint of its slack
+
+    u32 item = blockIdx.x * W + w;
+    bool have = item < a.n_items;
+    const float4 *gp = group_ptr(a, a.g_first + (have ? item : 0) * a.g_step) + lane;
+    float4 ring[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) ring[i] = gp[i * 64];
+    int par = 0;
+
+    for (u32 r = 0; r < nrounds; ++r) {
+        const u32 g = a.g_first + item * a.g_step;
+        const u32 nitem = item + stride;
+        const bool have_next = nitem < a.n_items;
+        const float4 *np = have_next ? group_ptr(a, a.g_first + nitem * a.g_step) + lane : gp;
+        f32x32 acc[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int e = 0; e < 32; ++e) acc[n][e] = 0.f;
+
+        for (int s = 0; s < NS; ++s) {
+            const int sn = (s + 1 == NS) ? 0 : s + 1;
+            float4 st[STG];
+#pragma unroll
+            for (int i = 0; i < STG; ++i) st[i] = qsrc[(size_t)sn * KC * NQ + tid + i * NTHR];
+            if (have) {
+                const float4 *qcur = qs + par * (KC * NQ) + jl;
+                const bool last = (s + 1 == NS);
+                // B fragments are software-pipelined one chunk ahead; sched_barrier keeps hipcc from
+                // hoisting a whole slice of LDS reads (64*NT VGPRs) above the MFMAs.
+                float4 bcur[NT], bnxt[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) bcur[n] = qcur[n * 32];
+#pragma unroll
+                for (int c = 0; c < KC; ++c) {
+                    if (c + 1 < KC) {
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) bnxt[n] = qcur[(c + 1) * NQ + n * 32];
+                    }
+                    const float4 av = ring[c % PF];
+                    const float4 *src = (last && c >= KC - PF) ? np + (c - (KC - PF)) * 64 : gp + (s * KC + c + PF) * 64;
+                    ring[c % PF] = *src;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        HAC_MFMA4_32(acc[n], av, bcur[n])
+                    }
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) bcur[n] = bnxt[n];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < STG; ++i) qs[(par ^ 1) * (KC * NQ) + tid + i * NTHR] = st[i];
+            __syncthreads();
+            par ^= 1;
+        }
+        gp = np;
+
+        // ---- epilogue: threshold filter, overflow-safe append, compaction by the owning waves
+        u32 pend[NT];
+        {
+            const long rem = a.n_rows - (long)g * GROUP_ROWS;
+            const int rows_valid = rem < GROUP_ROWS ? (int)rem : GROUP_ROWS;
+            const int rbase = 4 * (lane >> 5);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                pend[n] = 0u;
+                const float th = thr[n * 32 + jl];
+                if (have) {
+#pragma unroll
+                    for (int e = 0; e < 32; ++e) {
+                        const int row = 32 * (e >> 4) + (e & 3) + 8 * ((e >> 2) & 3) + rbase;
+                        if (acc[n][e] >= th && row < rows_valid) pend[n] |= (1u << e);
+                    }
+                }
+            }
+        }
+        for (;;) {
+            bool anyp = false;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) anyp |= (pend[n] != 0u);
+            if (__any(anyp)) {
+                // Rare path.  The tile's scores are copied to a per-lane scratch array so that the
+                // survivors can be walked with a run-time loop over the set bits; an unrolled
+                // 32*NT-way append would cost ~80 VGPRs in the hot loop's allocation.
+                const int rbase = 4 * (lane >> 5);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    if (pend[n] != 0u) {
+                        float sc[32];
+#pragma unroll
+                        for (int e = 0; e < 32; ++e) sc[e] = acc[n][e];
+                        const int j = n * 32 + jl;
+                        u32 m = pend[n];
+                        while (m) {
+                            const int e = __builtin_ctz(m);
+                            m &= m - 1u;
+                            const u32 pos = atomicAdd(&cnt[j], 1u);
+                            if (pos < (u32)C) {
+                                const int row = 32 * (e >> 4) + (e & 3) + 8 * ((e >> 2) & 3) + rbase;
+                                cand[(size_t)j * C + pos] = make_key(sc[e], a.pos_base + g * GROUP_ROWS + row);
+                                pend[n] &= ~(1u << e);
+                            } else {
+                                *ovf = 1u;
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();  // (B) appends of this pass visible, overflow flag final
+            const bool over = (*ovf != 0u);
+            for (int jj = w; jj < NQr; jj += W) {
+                u32 n = cnt[jj];
+                if (n > (u32)C) n = (u32)C;
+                float t_new = -INFINITY;
+                const bool compact = n > hw;  // wave-uniform; a full buffer (n == C) always compacts
+                if (compact) {
+                    wave_sort_desc(cand + (size_t)jj * C, n, lane);
+                    t_new = ord2f((u32)(cand[(size_t)jj * C + a.k - 1] >> 32));
+                }
+                if (lane == 0) {
+                    float t_cur = thr[jj];
+                    if (compact) {
+                        cnt[jj] = a.k;
+                        if (t_new > t_cur) {
+                            t_cur = t_new;
+                            atomicMax(&a.thr_glob[q0 + jj], f2ord(t_new));
+                        }
+                    }
+                    const u32 go = __hip_atomic_load(&a.thr_glob[q0 + jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (go != 0u) t_cur = fmaxf(t_cur, ord2f(go));
+                    thr[jj] = t_cur;
+                }
+            }
+            __syncthreads();  // (A) compactions done, thresholds final
+            if (!over) break;  // workgroup-uniform
+            if (tid == 0) *ovf = 0u;
+            // re-filter what is still pending against the raised thresholds, then offer it again
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                if (pend[n] == 0u) continue;
+                const float th = thr[n * 32 + jl];
+#pragma unroll
+                for (int e = 0; e < 32; ++e)
+                    if ((pend[n] & (1u << e)) && !(acc[n][e] >= th)) pend[n] &= ~(1u << e);
+            }
+            __syncthreads();  // flag reset ordered before the next pass's overflow stores
+        }
+        item = nitem;
+        have = have_next;
+    }
+
+    for (int jj = w; jj < NQr; jj += W) {
+        u32 n = cnt[jj];
+        if (n > (u32)C) n = (u32)C;
+        u64 *b = cand + (size_t)jj * C;
+        if (n > 1) wave_sort_desc(b, n, lane);
+        u64 *out = a.partial + ((size_t)(q0 + jj) * gridDim.x + blockIdx.x) * a.k;
+        const u32 keep = n < (u32)a.k ? n : (u32)a.k;
+        for (u32 i = lane; i < (u32)a.k; i += 64) out[i] = i < keep ? b[i] : 0ull;
+    }
+}
+
 // ------------------------------------------------------------------ merge kernel
 // One workgroup per query: streams L lists of k keys, keeps the k largest.
 // Element (l, q, i) lives at lists[l*stride_l + q*stride_q + i].
@@ -393,7 +626,7 @@ struct DeviceIndex {
     int64_t ntotal = 0;
     SegDesc *d_segs = nullptr;
     bool segs_dirty = true;
-    GrowBuf ws_partial, ws_seedkeys, ws_thr, ws_thrglob, ws_q, ws_keys, ws_D, ws_I, ws_stage[2];
+    GrowBuf ws_partial, ws_seedkeys, ws_thr, ws_thrglob, ws_q, ws_qt, ws_keys, ws_D, ws_I, ws_stage[2];
     void *h_stage[2] = {nullptr, nullptr};
     size_t h_stage_bytes = 0;
     // Small host<->device traffic (queries, results, segment table) always goes through
@@ -436,6 +669,10 @@ struct DeviceIndex {
                                         (int)LDS_LIMIT));
             HAC_HIP(hipFuncSetAttribute((const void *)merge_keys_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)(64 * 1024)));
+            const void *fq[] = {(const void *)scanq_kernel<1, 4>, (const void *)scanq_kernel<2, 4>, (const void *)scanq_kernel<3, 4>,
+                                (const void *)scanq_kernel<4, 4>, (const void *)scanq_kernel<1, 8>, (const void *)scanq_kernel<2, 8>,
+                                (const void *)scanq_kernel<3, 8>, (const void *)scanq_kernel<4, 8>};
+            for (const void *f : fq) HAC_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
             attr_done[device] = true;
         }
         return HAC_OK;
@@ -450,7 +687,7 @@ struct DeviceIndex {
         if (d_segs) (void)hipFree(d_segs);
         if (h_segs) (void)hipHostFree(h_segs);
         if (h_pin) (void)hipHostFree(h_pin);
-        for (GrowBuf *b : {&ws_partial, &ws_seedkeys, &ws_thr, &ws_thrglob, &ws_q, &ws_keys, &ws_D, &ws_I, &ws_stage[0],
+        for (GrowBuf *b : {&ws_partial, &ws_seedkeys, &ws_thr, &ws_thrglob, &ws_q, &ws_qt, &ws_keys, &ws_D, &ws_I, &ws_stage[0],
                            &ws_stage[1]})
             b->release();
         for (int i = 0; i < 2; ++i) {
@@ -606,32 +843,70 @@ struct DeviceIndex {
     int nseg_live = 0;
 
     struct Plan {
+        int kind;  // 0: scan16 (<=16 queries per workgroup, Q resident in LDS)   1: scanq<NT,W>
+        int NT, W;
         int QT, C, n_qtiles, P, Cm;
         size_t lds_scan, lds_merge;
     };
 
+    static size_t scanq_lds(int NQ, int C) { return (size_t)NQ * (2 * 16 * 16 + (size_t)C * 8 + 8) + 16; }
+
     int make_plan(int64_t nq, int k, u32 n_items, Plan &pl) const {
-        pl.C = (int)next_pow2((u32)k + 64u * SCAN_WAVES);
-        const size_t per_q = (size_t)K4 * 16 + (size_t)pl.C * 8;
-        const size_t fixed = 16 * 4 + 16 * 4;
-        int qt = (int)std::min<size_t>(16, (LDS_LIMIT - fixed) / per_q);
-        if (qt < 1) return fail(HAC_ERR_UNSUPPORTED, "k=%d with d=%d does not fit the LDS candidate buffers", k, d);
-        qt = (int)std::min<int64_t>(qt, nq);
-        pl.QT = qt;
-        pl.lds_scan = per_q * qt + fixed;
-        pl.n_qtiles = (int)((nq + qt - 1) / qt);
+        pl.kind = 0;
+        pl.NT = 0;
+        pl.W = SCAN_WAVES;
+        // many queries: GEMM-shaped kernel, NQ = 32*NT queries per workgroup
+        const char *force = getenv("HAC_FORCE_SCAN16");
+        if (nq > 16 && K4 % 16 == 0 && !(force && force[0] == '1')) {
+            const int C2 = (int)std::max<u32>(32u, next_pow2((u32)k + 1u));
+            int best_nt = 0;
+            int64_t best_pad = 0;
+            for (int nt = 1; nt <= 4; ++nt) {
+                if (scanq_lds(32 * nt, C2) > LDS_LIMIT) break;
+                const int64_t pad = (nq + 32 * nt - 1) / (32 * nt) * (32 * nt);
+                if (best_nt == 0 || pad <= best_pad) {
+                    best_nt = nt;
+                    best_pad = pad;
+                }
+            }
+            if (best_nt) {
+                pl.kind = 1;
+                pl.NT = best_nt;
+                const char *we = getenv("HAC_SCANQ_WAVES");
+                pl.W = (we && we[0] == '4') ? 4 : 8;
+                pl.QT = 32 * best_nt;
+                pl.C = C2;
+                pl.lds_scan = scanq_lds(pl.QT, C2);
+            }
+        }
+        if (pl.kind == 0) {
+            pl.C = (int)next_pow2((u32)k + 64u * SCAN_WAVES);
+            const size_t per_q = (size_t)K4 * 16 + (size_t)pl.C * 8;
+            const size_t fixed = 16 * 4 + 16 * 4;
+            int qt = (int)std::min<size_t>(16, (LDS_LIMIT - fixed) / per_q);
+            if (qt < 1) return fail(HAC_ERR_UNSUPPORTED, "k=%d with d=%d does not fit the LDS candidate buffers", k, d);
+            qt = (int)std::min<int64_t>(qt, nq);
+            pl.QT = qt;
+            pl.lds_scan = per_q * qt + fixed;
+        }
+        pl.n_qtiles = (int)((nq + pl.QT - 1) / pl.QT);
         // resident workgroups: LDS- and wave-limited
-        int per_cu = (int)std::min<size_t>(LDS_LIMIT / pl.lds_scan, 32 / SCAN_WAVES);
-        per_cu = std::max(1, std::min(per_cu, 4));
+        int per_cu = (int)std::min<size_t>(LDS_LIMIT / pl.lds_scan, 32 / pl.W);
+        per_cu = std::max(1, std::min(per_cu, pl.kind == 1 ? 2 : 4));
         const long resident = (long)n_cu * per_cu;
         long P = std::max<long>(1, resident / pl.n_qtiles);
         if (P >= 8) P = P / 8 * 8;  // same-row workgroups of different query tiles share an XCD (L2)
-        const long maxP = (n_items + SCAN_WAVES - 1) / SCAN_WAVES;
+        const long maxP = (n_items + pl.W - 1) / pl.W;
         P = std::max<long>(1, std::min(P, maxP));
         pl.P = (int)P;
         pl.Cm = (int)next_pow2((u32)k + MERGE_THREADS);
         pl.lds_merge = (size_t)pl.Cm * 8 + 32;
         return HAC_OK;
+    }
+
+    template <int NT, int W>
+    static void launch_scanq(const ScanArgs &a, int P, int n_qtiles, size_t lds, hipStream_t st) {
+        scanq_kernel<NT, W><<<dim3((unsigned)P, (unsigned)n_qtiles), dim3(W * 64), lds, st>>>(a);
     }
 
     int run_scan(const Plan &pl, const float *q_dev, int64_t nq, int k, u32 g_first, u32 g_step, u32 n_items,
@@ -640,6 +915,7 @@ struct DeviceIndex {
         a.segs = d_segs;
         a.nseg = nseg_live;
         a.q = reinterpret_cast<const float4 *>(q_dev);
+        a.qt = reinterpret_cast<const float4 *>(ws_qt.p);
         a.nq = (int)nq;
         a.K4 = K4;
         a.k = k;
@@ -653,7 +929,7 @@ struct DeviceIndex {
         a.thr_glob = (u32 *)ws_thrglob.p;
         a.partial = (u64 *)ws_partial.p;
         a.pos_base = pos_base;
-        HAC_HIP(hipMemsetAsync(ws_thrglob.p, 0, (size_t)nq * 4, st));
+        HAC_HIP(hipMemsetAsync(ws_thrglob.p, 0, (size_t)pl.n_qtiles * pl.QT * 4, st));
         if (timed) {
             if (ev_used == ev_pool.size()) {
                 hipEvent_t a0, a1;
@@ -663,7 +939,22 @@ struct DeviceIndex {
             }
             HAC_HIP(hipEventRecord(ev_pool[ev_used].first, st));
         }
-        scan16_kernel<<<dim3((unsigned)P, (unsigned)pl.n_qtiles), dim3(SCAN_WAVES * 64), pl.lds_scan, st>>>(a);
+        if (pl.kind == 0) {
+            scan16_kernel<<<dim3((unsigned)P, (unsigned)pl.n_qtiles), dim3(SCAN_WAVES * 64), pl.lds_scan, st>>>(a);
+        } else {
+            const int key = pl.NT * 10 + pl.W;
+            switch (key) {
+                case 14: launch_scanq<1, 4>(a, P, pl.n_qtiles, pl.lds_scan, st); break;
+                case 24: launch_scanq<2, 4>(a, P, pl.n_qtiles, pl.lds_scan, st); break;
+                case 34: launch_scanq<3, 4>(a, P, pl.n_qtiles, pl.lds_scan, st); break;
+                case 44: launch_scanq<4, 4>(a, P, pl.n_qtiles, pl.lds_scan, st); break;
+                case 18: launch_scanq<1, 8>(a, P, pl.n_qtiles, pl.lds_scan, st); break;
+                case 28: launch_scanq<2, 8>(a, P, pl.n_qtiles, pl.lds_scan, st); break;
+                case 38: launch_scanq<3, 8>(a, P, pl.n_qtiles, pl.lds_scan, st); break;
+                case 48: launch_scanq<4, 8>(a, P, pl.n_qtiles, pl.lds_scan, st); break;
+                default: return fail(HAC_ERR_UNSUPPORTED, "internal: no scanq<%d,%d>", pl.NT, pl.W);
+            }
+        }
         HAC_HIP(hipGetLastError());
         if (timed) {
             HAC_HIP(hipEventRecord(ev_pool[ev_used].second, st));
@@ -694,7 +985,14 @@ struct DeviceIndex {
         Plan pl;
         HAC_TRY(make_plan(nq, k, G, pl));
         HAC_TRY(ws_partial.reserve((size_t)nq * pl.P * k * 8));
-        HAC_TRY(ws_thrglob.reserve((size_t)nq * 4));
+        HAC_TRY(ws_thrglob.reserve((size_t)pl.n_qtiles * pl.QT * 4));
+        if (pl.kind == 1) {
+            const long total = (long)pl.n_qtiles * K4 * pl.QT;
+            HAC_TRY(ws_qt.reserve((size_t)total * 16));
+            retile_queries_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(
+                reinterpret_cast<const float4 *>(q_dev), (int)nq, K4, pl.QT, pl.n_qtiles, (float4 *)ws_qt.p);
+            HAC_HIP(hipGetLastError());
+        }
         const float *thr_init = nullptr;
         // Threshold seeding: exact top-k of an evenly strided sample of groups gives a
         // lower bound of every query's final k-th score; it only filters, never decides.
@@ -703,7 +1001,7 @@ struct DeviceIndex {
             HAC_TRY(ws_seedkeys.reserve((size_t)nq * k * 8));
             HAC_TRY(ws_thr.reserve((size_t)nq * 4));
             const u32 step = G / n_sample;
-            const int Ps = (int)std::max<long>(1, std::min<long>(pl.P, (n_sample + SCAN_WAVES - 1) / SCAN_WAVES));
+            const int Ps = (int)std::max<long>(1, std::min<long>(pl.P, (n_sample + pl.W - 1) / pl.W));
             HAC_TRY(run_scan(pl, q_dev, nq, k, 0, step, n_sample, nullptr, pos_base, Ps, st, false));
             HAC_TRY(run_merge(pl, (const u64 *)ws_partial.p, Ps, (size_t)k, (size_t)Ps * k, nq, k, (u64 *)ws_seedkeys.p,
                               (float *)ws_thr.p, st));

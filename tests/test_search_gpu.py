@@ -280,3 +280,53 @@ def test_full_size_cfg2_properties(oracle):
     oD, oI = oracle.flat_ip_search(xh, q[sel].cpu().numpy(), K)
     np.testing.assert_array_equal(I[sel].cpu().numpy(), oI)
     np.testing.assert_array_equal(D[sel].cpu().numpy(), oD)
+
+
+@pytest.mark.parametrize("nq,k", [(17, 100), (40, 10), (70, 120), (33, 1), (20, 300), (130, 100)])
+def test_adversarial_ascending_scores(nq, k, index, oracle):
+    """Rows sorted so that EVERY row beats everything before it for every query: thresholds never
+    filter, candidate buffers overflow every round (the overflow/re-offer protocol of scanq_kernel
+    and the per-round compaction of scan16_kernel carry the whole result)."""
+    n = 6000
+    base = cases.search_case_inputs("gauss", 2024, 1, nq)[1]          # [nq, 768] query vectors
+    x = np.zeros((n, 768), np.float32)
+    scale = (np.arange(n, dtype=np.float32) + 1.0) / 64.0               # exactly representable, increasing
+    x[:, 0] = scale
+    q = base.copy()
+    q[:, 0] = np.abs(q[:, 0]) + 1.0                                     # positive weight on the increasing coordinate
+    q[:, 1:] = 0.0
+    index.reset()
+    index.add(x)
+    assert_same(*index.search(q, k), *oracle.flat_ip_search(x, q, k))
+    index.reset()                                                       # descending: the first rows win, later ones never pass
+    index.add(x[::-1].copy())
+    assert_same(*index.search(q, k), *oracle.flat_ip_search(x[::-1].copy(), q, k))
+
+
+def test_all_ties_many_queries(index, oracle):
+    x = np.ones((3000, 768), np.float32)
+    q = np.zeros((48, 768), np.float32)
+    q[:, 3] = np.linspace(-2, 2, 48).astype(np.float32)
+    index.reset()
+    index.add(x)
+    D, I = index.search(q, 100)
+    assert_same(D, I, *oracle.flat_ip_search(x, q, 100))
+    assert np.all(I == np.arange(100)[None, :])
+
+
+def test_scan16_and_scanq_agree(oracle, monkeypatch):
+    """The two scan kernels (<=16 queries resident in LDS vs. slice-staged 32*NT queries) are
+    different code paths for the same contract: forced through both, results must be identical."""
+    from haconvdr_amd.index import FlatIPIndex
+    x, q, _ = cases.search_case_inputs("gauss", 555, 12000, 50)
+    idx = FlatIPIndex(768)
+    idx.add(x)
+    D1, I1 = idx.search(q, 100)
+    monkeypatch.setenv("HAC_FORCE_SCAN16", "1")
+    D2, I2 = idx.search(q, 100)
+    monkeypatch.delenv("HAC_FORCE_SCAN16")
+    monkeypatch.setenv("HAC_SCANQ_WAVES", "4")
+    D3, I3 = idx.search(q, 100)
+    oD, oI = oracle.flat_ip_search(x, q, 100)
+    for D, I in ((D1, I1), (D2, I2), (D3, I3)):
+        assert_same(D, I, oD, oI)
