@@ -101,6 +101,8 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     scan_ms = index.profile_drain()
+    plan = index.last_plan()
+    kname = plan.split(" ")[0]
     index.set_profiling(False)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -129,12 +131,12 @@ def main():
         except Exception:
             traffic = None
     if mfma_bound:
-        roofline = {"kernel": "scan16_kernel", "bound": "mfma", "achieved": round(mfma_tf, 2), "peak": PEAK_F32_MFMA_TF,
+        roofline = {"kernel": kname, "plan": plan, "bound": "mfma", "achieved": round(mfma_tf, 2), "peak": PEAK_F32_MFMA_TF,
                     "unit": "TFLOP/s", "frac": round(mfma_tf / PEAK_F32_MFMA_TF, 4), "traffic": traffic,
                     "kernel_ms": round(scan_avg_ms, 4), "hbm_GBps_same_kernel": round(hbm_gbs, 1),
                     "hbm_frac_same_kernel": round(hbm_gbs / PEAK_HBM_GBS, 4)}
     else:
-        roofline = {"kernel": "scan16_kernel", "bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": PEAK_HBM_GBS,
+        roofline = {"kernel": kname, "plan": plan, "bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": PEAK_HBM_GBS,
                     "unit": "GB/s", "frac": round(hbm_gbs / PEAK_HBM_GBS, 4), "traffic": traffic,
                     "kernel_ms": round(scan_avg_ms, 4), "mfma_TFLOPs_same_kernel": round(mfma_tf, 2)}
 
@@ -153,9 +155,10 @@ def main():
         torch.cuda.synchronize()
         dt16 = (time.perf_counter() - t1) / reps
         ms16 = float(np.mean(index.profile_drain()))
+        plan16 = index.last_plan()
         index.set_profiling(False)
         b16 = n_local * D_EMB * 4 + 16 * D_EMB * 4 + 16 * args.k * 12
-        hbm_regime = {"nq": 16, "kernel_ms": round(ms16, 4), "search_ms": round(dt16 * 1e3, 4),
+        hbm_regime = {"nq": 16, "plan": plan16, "kernel_ms": round(ms16, 4), "search_ms": round(dt16 * 1e3, 4),
                       "achieved_GBps": round(b16 / (ms16 * 1e-3) / 1e9, 1),
                       "frac_of_8TBps": round(b16 / (ms16 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                       "queries_per_sec": round(16 / dt16, 1)}

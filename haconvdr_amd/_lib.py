@@ -40,6 +40,8 @@ def _declare(L):
     L.hac_index_ntotal.restype = i64
     L.hac_index_set_profiling.argtypes = [vp, ctypes.c_int]
     L.hac_index_profile_drain.argtypes = [vp, c_f32p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    L.hac_index_last_plan.argtypes = [vp]
+    L.hac_index_last_plan.restype = ctypes.c_char_p
     L.hac_merge_keys_device.argtypes = [ctypes.c_int, vp, ctypes.c_int, i64, ctypes.c_int, vp, vp]
     L.hac_keys_to_results_device.argtypes = [ctypes.c_int, vp, i64, vp, vp, vp, vp]
     for name in ("hac_index_create", "hac_index_add", "hac_index_add_device", "hac_index_search",
@@ -53,7 +55,7 @@ def _declare(L):
 EXPORTED_SYMBOLS = (
     "hac_last_error", "hac_version", "hac_index_create", "hac_index_destroy", "hac_index_add",
     "hac_index_add_device", "hac_index_search", "hac_index_search_device", "hac_index_search_keys_device",
-    "hac_index_reset", "hac_index_ntotal", "hac_index_set_profiling", "hac_index_profile_drain",
+    "hac_index_reset", "hac_index_ntotal", "hac_index_set_profiling", "hac_index_profile_drain", "hac_index_last_plan",
     "hac_merge_keys_device", "hac_keys_to_results_device",
 )
 

@@ -841,6 +841,7 @@ struct DeviceIndex {
         return HAC_OK;
     }
     int nseg_live = 0;
+    char last_plan[160] = "none";
 
     struct Plan {
         int kind;  // 0: scan16 (<=16 queries per workgroup, Q resident in LDS)   1: scanq<NT,W>
@@ -1007,6 +1008,12 @@ struct DeviceIndex {
                               (float *)ws_thr.p, st));
             thr_init = (const float *)ws_thr.p;
         }
+        if (pl.kind == 1)
+            snprintf(last_plan, sizeof last_plan, "scanq_kernel<NT=%d,W=%d> grid=(%d,%d) NQ=%d C=%d lds=%zu seed=%d", pl.NT, pl.W, pl.P,
+                     pl.n_qtiles, pl.QT, pl.C, pl.lds_scan, thr_init ? 1 : 0);
+        else
+            snprintf(last_plan, sizeof last_plan, "scan16_kernel<W=%d> grid=(%d,%d) QT=%d C=%d lds=%zu seed=%d", SCAN_WAVES, pl.P,
+                     pl.n_qtiles, pl.QT, pl.C, pl.lds_scan, thr_init ? 1 : 0);
         HAC_TRY(run_scan(pl, q_dev, nq, k, 0, 1, G, thr_init, pos_base, pl.P, st, profiling));
         HAC_TRY(run_merge(pl, (const u64 *)ws_partial.p, pl.P, (size_t)k, (size_t)pl.P * k, nq, k, keys_out, nullptr, st));
         return HAC_OK;
@@ -1238,6 +1245,10 @@ int hac_index_set_profiling(hac_index *idx, int enable) {
     if (!idx) return fail(HAC_ERR_INVALID, "null index");
     for (auto *s : idx->shards) s->profiling = enable != 0;
     return HAC_OK;
+}
+
+const char *hac_index_last_plan(const hac_index *idx) {
+    return (idx && !idx->shards.empty()) ? idx->shards[0]->last_plan : "none";
 }
 
 int hac_index_profile_drain(hac_index *idx, float *ms_out, int cap, int *n_out) {

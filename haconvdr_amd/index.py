@@ -107,6 +107,9 @@ class FlatIPIndex:
     def set_profiling(self, on=True):
         _lib.check(_lib.lib().hac_index_set_profiling(self._h, int(bool(on))))
 
+    def last_plan(self):
+        return _lib.lib().hac_index_last_plan(self._h).decode()
+
     def profile_drain(self, cap=4096):
         """Durations (ms) of the main scan kernel of every search since the last drain."""
         buf = (ctypes.c_float * cap)()

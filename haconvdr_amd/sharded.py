@@ -45,9 +45,10 @@ class ShardedSearcher:
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         if world == 1:
             return keys
-        gathered = torch.empty((world,) + tuple(keys.shape), dtype=keys.dtype, device=keys.device)
+        nq, k = keys.shape
+        gathered = torch.empty((world * nq, k), dtype=keys.dtype, device=keys.device)   # rank-major slabs
         dist.all_gather_into_tensor(gathered, keys.contiguous(), group=self.group)
-        return self._merge(gathered)
+        return self._merge(gathered.view(world, nq, k))
 
     def search(self, q, k):
         return self._to_results(self.search_keys(q, k), self.id_map)

@@ -99,6 +99,9 @@ int64_t hac_index_ntotal(const hac_index *idx);
  * durations (ms, in launch order) to ms_out, sets *n_out and clears the record. */
 int hac_index_set_profiling(hac_index *idx, int enable);
 int hac_index_profile_drain(hac_index *idx, float *ms_out, int cap, int *n_out);
+/* Human-readable description of the kernel configuration of the most recent search
+ * (kernel name, grid, queries per workgroup, candidate slots, LDS bytes). */
+const char *hac_index_last_plan(const hac_index *idx);
 
 /* ------------------------------------------------------- top-k list merging */
 /* K9: merge L per-block / per-shard key lists into one.  lists_dev: uint64
