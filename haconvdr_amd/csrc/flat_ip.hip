@@ -78,6 +78,16 @@ __device__ __forceinline__ u64 make_key(float s, u32 pos) {
     return ((u64)f2ord(s) << 32) | (u64)(0xFFFFFFFFu - pos);
 }
 
+// Pointers that reach a kernel through memory (segment table, ScanArgs) are generic to the
+// compiler, which then emits flat_load + "vmcnt(0) lgkmcnt(0)" drains.  Loading through an
+// explicit global (address_space(1)) pointer gives global_load and counted vmcnt waits.  The
+// cast must happen where the pointer is formed: cast at the load site after a select of two
+// generic pointers, hipcc (ROCm 7.2) falls back to flat_load.
+// f4: plain 4-float vector (HIP's float4 class cannot be copied out of address_space(1)).
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) f4 *gf4ptr;
+__device__ __forceinline__ gf4ptr as_global(const float4 *p) { return (gf4ptr)(p); }
+
 __device__ __forceinline__ void lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
 
 // In-LDS bitonic sort, descending, by ONE wave.  buf has capacity >= next_pow2(n).
@@ -170,10 +180,10 @@ struct ScanArgs {
     u32 pos_base;
 };
 
-__device__ __forceinline__ const float4 *group_ptr(const ScanArgs &a, u32 g) {
+__device__ __forceinline__ gf4ptr group_ptr(const ScanArgs &a, u32 g) {
     int s = 0;
     while (s + 1 < a.nseg && g >= a.segs[s + 1].gstart) ++s;
-    return a.segs[s].ptr + (size_t)(g - a.segs[s].gstart) * a.K4 * GROUP_ROWS;
+    return as_global(a.segs[s].ptr) + (size_t)(g - a.segs[s].gstart) * a.K4 * GROUP_ROWS;
 }
 
 #define HAC_MFMA4(av, bv)                                                        \
@@ -192,14 +202,14 @@ __global__ __launch_bounds__(SCAN_WAVES * 64) void scan16_kernel(ScanArgs a) {
     const int QTr = min(a.QT, a.nq - q0);
     const int C = a.C;
 
-    float4 *ldsQ = reinterpret_cast<float4 *>(smem);                       // [K4][QTr]
+    f4 *ldsQ = reinterpret_cast<f4 *>(smem);                       // [K4][QTr]
     u64 *cand = reinterpret_cast<u64 *>(smem + (size_t)K4 * QTr * 16);     // [QTr][C]
     u32 *cnt = reinterpret_cast<u32 *>(cand + (size_t)QTr * C);            // [16]
     float *thr = reinterpret_cast<float *>(cnt + 16);                      // [16]
 
     for (int idx = tid; idx < K4 * QTr; idx += SCAN_WAVES * 64) {
         const int k4 = idx / QTr, j = idx - k4 * QTr;
-        ldsQ[idx] = a.q[(size_t)(q0 + j) * K4 + k4];
+        ldsQ[idx] = as_global(a.q)[(size_t)(q0 + j) * K4 + k4];
     }
     if (tid < 16) {
         cnt[tid] = 0;
@@ -209,15 +219,15 @@ __global__ __launch_bounds__(SCAN_WAVES * 64) void scan16_kernel(ScanArgs a) {
 
     const int j = lane & 15;
     const int jc = min(j, QTr - 1);
-    const float4 *qb = ldsQ + jc;
+    const f4 *qb = ldsQ + jc;
     const u32 stride = gridDim.x * SCAN_WAVES;
     const u32 nrounds = (a.n_items + stride - 1) / stride;
     const u32 hw = (u32)C - 64u * SCAN_WAVES;  // compaction high-water mark (>= k)
 
     u32 item = blockIdx.x * SCAN_WAVES + w;
     bool have = item < a.n_items;
-    const float4 *gp = group_ptr(a, a.g_first + (have ? item : 0) * a.g_step) + lane;
-    float4 ring[PF];
+    gf4ptr gp = group_ptr(a, a.g_first + (have ? item : 0) * a.g_step) + lane;
+    f4 ring[PF];
 #pragma unroll
     for (int i = 0; i < PF; ++i) ring[i] = gp[i * 64];
 
@@ -227,25 +237,38 @@ __global__ __launch_bounds__(SCAN_WAVES * 64) void scan16_kernel(ScanArgs a) {
         const bool have_next = nitem < a.n_items;
         f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (have) {
-            const float4 *np = have_next ? group_ptr(a, a.g_first + nitem * a.g_step) + lane : gp;
+            gf4ptr np = have_next ? group_ptr(a, a.g_first + nitem * a.g_step) + lane : gp;
             const int NB = K4 / PF;
+            // clean entry state for the chunk loop (see scanq_kernel): counted vmcnt(PF-1) inside
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only, once per group
+            // B (query) fragments run one chunk ahead of the MFMAs; the sched_barrier after every
+            // chunk pins "consume ring[i] -> refill ring[i]" in program order, otherwise hipcc
+            // clusters the eight refills at the end of the block and waits vmcnt(0) on them.
+            f4 bcur = qb[0], bnxt;
             for (int tb = 0; tb < NB - 1; ++tb) {
 #pragma unroll
                 for (int i = 0; i < PF; ++i) {
                     const int t = tb * PF + i;
-                    const float4 av = ring[i];
+                    bnxt = qb[(t + 1) * QTr];
+                    const f4 av = ring[i];
+                    HAC_MFMA4(av, bcur)
+                    // refill AFTER the MFMAs that read ring[i]: the load can then reuse the register;
+                    // issued before them it gets a fresh one and hipcc copies it back at the loop
+                    // end behind vmcnt(7)...vmcnt(0) — a full drain every PF chunks
                     ring[i] = gp[(t + PF) * 64];
-                    const float4 bv = qb[t * QTr];
-                    HAC_MFMA4(av, bv)
+                    bcur = bnxt;
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
 #pragma unroll
             for (int i = 0; i < PF; ++i) {
                 const int t = (NB - 1) * PF + i;
-                const float4 av = ring[i];
+                bnxt = qb[(i + 1 < PF ? t + 1 : 0) * QTr];
+                const f4 av = ring[i];
+                HAC_MFMA4(av, bcur)
                 ring[i] = np[i * 64];  // next group's first chunks stay in flight across the epilogue
-                const float4 bv = qb[t * QTr];
-                HAC_MFMA4(av, bv)
+                bcur = bnxt;
+                __builtin_amdgcn_sched_barrier(0);
             }
             gp = np;
         }
@@ -358,12 +381,12 @@ __global__ __launch_bounds__(W * 64) void scanq_kernel(ScanArgs a) {
     const int NQr = min(NQ, a.nq - q0);
     const int C = a.C;
 
-    float4 *qs = reinterpret_cast<float4 *>(smem);                         // [2][KC][NQ]
+    f4 *qs = reinterpret_cast<f4 *>(smem);                         // [2][KC][NQ]
     u64 *cand = reinterpret_cast<u64 *>(smem + (size_t)2 * KC * NQ * 16);  // [NQ][C]
     u32 *cnt = reinterpret_cast<u32 *>(cand + (size_t)NQ * C);             // [NQ]
     float *thr = reinterpret_cast<float *>(cnt + NQ);                      // [NQ]
     u32 *ovf = reinterpret_cast<u32 *>(thr + NQ);                          // [1]
-    const float4 *qsrc = a.qt + (size_t)blockIdx.y * K4 * NQ;
+    gf4ptr qsrc = as_global(a.qt) + (size_t)blockIdx.y * K4 * NQ;
 
     for (int i = tid; i < NQ; i += NTHR) {
         cnt[i] = 0;
@@ -381,8 +404,8 @@ __global__ __launch_bounds__(W * 64) void scanq_kernel(ScanArgs a) {
 
     u32 item = blockIdx.x * W + w;
     bool have = item < a.n_items;
-    const float4 *gp = group_ptr(a, a.g_first + (have ? item : 0) * a.g_step) + lane;
-    float4 ring[PF];
+    gf4ptr gp = group_ptr(a, a.g_first + (have ? item : 0) * a.g_step) + lane;
+    f4 ring[PF];
 #pragma unroll
     for (int i = 0; i < PF; ++i) ring[i] = gp[i * 64];
     int par = 0;
@@ -391,24 +414,30 @@ __global__ __launch_bounds__(W * 64) void scanq_kernel(ScanArgs a) {
         const u32 g = a.g_first + item * a.g_step;
         const u32 nitem = item + stride;
         const bool have_next = nitem < a.n_items;
-        const float4 *np = have_next ? group_ptr(a, a.g_first + nitem * a.g_step) + lane : gp;
+        gf4ptr np = have_next ? group_ptr(a, a.g_first + nitem * a.g_step) + lane : gp;
         f32x32 acc[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int e = 0; e < 32; ++e) acc[n][e] = 0.f;
 
+        // One explicit drain per round gives the slice loop a clean entry state; without it hipcc's
+        // waitcnt pass merges the (unordered) epilogue state into the loop header and emits
+        // vmcnt(0) at the top of EVERY slice instead of the counted vmcnt(PF-1).
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
         for (int s = 0; s < NS; ++s) {
             const int sn = (s + 1 == NS) ? 0 : s + 1;
-            float4 st[STG];
-#pragma unroll
-            for (int i = 0; i < STG; ++i) st[i] = qsrc[(size_t)sn * KC * NQ + tid + i * NTHR];
-            if (have) {
-                const float4 *qcur = qs + par * (KC * NQ) + jl;
+            gf4ptr qnext = qsrc + (size_t)sn * KC * NQ + tid;
+            f4 st[STG];
+            // No `if (have)` around the slice: a wave without work (last round only) scores group 0
+            // again and discards it.  A branch here makes hipcc join the two paths before the LDS
+            // write and take the idle path's vmcnt(0), draining the prefetch ring every slice.
+            {
+                const f4 *qcur = qs + par * (KC * NQ) + jl;
                 const bool last = (s + 1 == NS);
                 // B fragments are software-pipelined one chunk ahead; sched_barrier keeps hipcc from
                 // hoisting a whole slice of LDS reads (64*NT VGPRs) above the MFMAs.
-                float4 bcur[NT], bnxt[NT];
+                f4 bcur[NT], bnxt[NT];
 #pragma unroll
                 for (int n = 0; n < NT; ++n) bcur[n] = qcur[n * 32];
 #pragma unroll
@@ -417,20 +446,25 @@ __global__ __launch_bounds__(W * 64) void scanq_kernel(ScanArgs a) {
 #pragma unroll
                         for (int n = 0; n < NT; ++n) bnxt[n] = qcur[(c + 1) * NQ + n * 32];
                     }
-                    const float4 av = ring[c % PF];
-                    const float4 *src = (last && c >= KC - PF) ? np + (c - (KC - PF)) * 64 : gp + (s * KC + c + PF) * 64;
-                    ring[c % PF] = *src;
+                    const f4 av = ring[c % PF];
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
                         HAC_MFMA4_32(acc[n], av, bcur[n])
+                    }
+                    // refill after the MFMAs that read the slot, so the load reuses its registers
+                    gf4ptr src = (last && c >= KC - PF) ? np + (c - (KC - PF)) * 64 : gp + (s * KC + c + PF) * 64;
+                    ring[c % PF] = *src;
+                    if (c == KC - 4) {  // next query slice: issued late so its registers live for 4 chunks only
+#pragma unroll
+                        for (int i = 0; i < STG; ++i) st[i] = qnext[i * NTHR];
                     }
 #pragma unroll
                     for (int n = 0; n < NT; ++n) bcur[n] = bnxt[n];
                     __builtin_amdgcn_sched_barrier(0);
                 }
-            }
 #pragma unroll
-            for (int i = 0; i < STG; ++i) qs[(par ^ 1) * (KC * NQ) + tid + i * NTHR] = st[i];
+                for (int i = 0; i < STG; ++i) qs[(par ^ 1) * (KC * NQ) + tid + i * NTHR] = st[i];
+            }
             __syncthreads();
             par ^= 1;
         }
