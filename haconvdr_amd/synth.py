@@ -86,3 +86,72 @@ def token_batch(seed, batch, max_len, min_len=8, vocab=50265, fixed_len=None):
     ids[pos == (lens[:, None] - 1)] = 2
     ids[pos >= lens[:, None]] = 0
     return ids, lens
+
+
+def normal_fast(seed, shape, std=1.0):
+    """float32 pseudo-normal from FOUR 16-bit uniforms of one splitmix64 word (Irwin–Hall n=4,
+    bounded at ±3.46 sd).  3x cheaper than ``normal``; used for the 125 M synthetic encoder weights."""
+    n = int(np.prod(shape))
+    w = _stream(seed, n, 7)
+    acc = np.zeros(n, np.int64)
+    for s in (0, 16, 32, 48):
+        acc += ((w >> np.uint64(s)) & np.uint64(0xFFFF)).astype(np.int64)
+    # mean 4*32767.5 = 131070, sd = 65536/sqrt(3)
+    return (((acc - 131070).astype(np.float64) * (np.sqrt(3.0) / 65536.0)) * float(std)).astype(np.float32).reshape(shape)
+
+
+def _name_seed(seed, name):
+    h = np.uint64(seed & 0xFFFFFFFFFFFFFFFF)
+    with np.errstate(over="ignore"):
+        for ch in name.encode():
+            h = _splitmix64(h ^ np.uint64(ch))
+    return int(h)
+
+
+def ance_state_dict(seed=0xA11CE, n_layers=12, hidden=768, ffn=3072, vocab=50265, max_pos=514, rich=True):
+    """Synthetic weights with the reference checkpoint's key names (``roberta.*``,
+    ``embeddingHead.*``, ``norm.*``): dict name -> float32 ndarray.
+
+    Matrices ~ N(0, 0.02²) (the reference's init, src/models.py:37).  rich=True also randomises
+    biases (sd 0.02) and LayerNorm affine (gamma 1 ± 0.1, beta sd 0.05) so that every parameter
+    influences the output — used by the parity tests; rich=False is the survey's bench recipe
+    (biases 0, LN identity)."""
+    sd = {}
+
+    def mat(name, shape):
+        sd[name] = normal_fast(_name_seed(seed, name), shape, 0.02)
+
+    def vec(name, n, kind):
+        if not rich:
+            sd[name] = np.ones(n, np.float32) if kind == "gamma" else np.zeros(n, np.float32)
+        elif kind == "gamma":
+            sd[name] = (1.0 + normal_fast(_name_seed(seed, name), (n,), 0.1)).astype(np.float32)
+        else:
+            sd[name] = normal_fast(_name_seed(seed, name), (n,), 0.05 if kind == "beta" else 0.02)
+
+    p = "roberta.embeddings."
+    mat(p + "word_embeddings.weight", (vocab, hidden))
+    mat(p + "position_embeddings.weight", (max_pos, hidden))
+    mat(p + "token_type_embeddings.weight", (1, hidden))
+    vec(p + "LayerNorm.weight", hidden, "gamma")
+    vec(p + "LayerNorm.bias", hidden, "beta")
+    for i in range(n_layers):
+        q = f"roberta.encoder.layer.{i}."
+        for nm in ("query", "key", "value"):
+            mat(q + f"attention.self.{nm}.weight", (hidden, hidden))
+            vec(q + f"attention.self.{nm}.bias", hidden, "bias")
+        mat(q + "attention.output.dense.weight", (hidden, hidden))
+        vec(q + "attention.output.dense.bias", hidden, "bias")
+        vec(q + "attention.output.LayerNorm.weight", hidden, "gamma")
+        vec(q + "attention.output.LayerNorm.bias", hidden, "beta")
+        mat(q + "intermediate.dense.weight", (ffn, hidden))
+        vec(q + "intermediate.dense.bias", ffn, "bias")
+        mat(q + "output.dense.weight", (hidden, ffn))
+        vec(q + "output.dense.bias", hidden, "bias")
+        vec(q + "output.LayerNorm.weight", hidden, "gamma")
+        vec(q + "output.LayerNorm.bias", hidden, "beta")
+    mat("embeddingHead.weight", (768, hidden))
+    vec("embeddingHead.bias", 768, "bias")
+    vec("norm.weight", 768, "gamma")
+    vec("norm.bias", 768, "beta")
+    return sd

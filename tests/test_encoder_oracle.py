@@ -1,0 +1,52 @@
+"""The encoder oracle (fp32 torch restatement) against goldens produced by the REFERENCE's own
+models.ANCE (tests/golden/make_golden_encoder.py).  CPU only; the 12-layer cases take ~20 s."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "encoder_*.npz")))
+_SD = {}
+
+
+def state_dict(n_layers):
+    from haconvdr_amd import synth
+    if n_layers not in _SD:
+        _SD[n_layers] = synth.ance_state_dict(0xA11CE, n_layers)
+    return _SD[n_layers]
+
+
+def cosine(a, b):
+    return (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+
+
+def test_encoder_goldens_present():
+    assert len(GOLD) >= 4
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[8:-4] for p in GOLD])
+def test_oracle_matches_reference_ance(path):
+    from oracle import ance_oracle
+    g = np.load(path)
+    out = ance_oracle.ance_forward(state_dict(int(g["n_layers"])), g["ids"].astype(np.int64), g["mask"].astype(np.int64))
+    ref = g["ref_out"]
+    assert out.shape == ref.shape == (len(g["lens"]), 768) and out.dtype == np.float32
+    # fp32 vs fp32 (sdpa vs explicit softmax): tolerance 2e-4 absolute on outputs of norm ~27.7, cosine 1e-6
+    np.testing.assert_allclose(out, ref, atol=2e-4, rtol=0)
+    assert np.all(1.0 - cosine(out, ref) < 1e-6)
+    assert float(g["pad_invariance_maxdiff"]) == 0.0
+
+
+def test_oracle_varlen_equals_padded():
+    """Dropping the padded tail entirely (what the HIP varlen path does) changes nothing beyond fp32
+    reassociation noise."""
+    from oracle import ance_oracle
+    g = np.load([p for p in GOLD if "l2_mixed" in p][0])
+    sd = state_dict(2)
+    ids, mask, lens = g["ids"].astype(np.int64), g["mask"].astype(np.int64), g["lens"]
+    full = ance_oracle.ance_forward(sd, ids, mask)
+    for b in (0, 3, 5):
+        n = int(lens[b])
+        cut = ance_oracle.ance_forward(sd, ids[b:b + 1, :n], mask[b:b + 1, :n])
+        np.testing.assert_allclose(cut[0], full[b], atol=1e-4, rtol=0)
