@@ -44,6 +44,18 @@ def _declare(L):
     L.hac_index_last_plan.restype = ctypes.c_char_p
     L.hac_merge_keys_device.argtypes = [ctypes.c_int, vp, ctypes.c_int, i64, ctypes.c_int, vp, vp]
     L.hac_keys_to_results_device.argtypes = [ctypes.c_int, vp, i64, vp, vp, vp, vp]
+    L.hac_encoder_create.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp)]
+    L.hac_encoder_destroy.argtypes = [vp]
+    L.hac_encoder_destroy.restype = None
+    L.hac_encoder_set_weight.argtypes = [vp, ctypes.c_char_p, c_f32p, ctypes.c_size_t]
+    L.hac_encoder_finalize.argtypes = [vp]
+    L.hac_encoder_forward.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.c_int, ctypes.c_int, c_f32p]
+    L.hac_encoder_forward_device.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]
+    L.hac_encoder_set_profiling.argtypes = [vp, ctypes.c_int]
+    L.hac_encoder_profile_drain.argtypes = [vp, c_f32p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    for name in ("hac_encoder_create", "hac_encoder_set_weight", "hac_encoder_finalize", "hac_encoder_forward",
+                 "hac_encoder_forward_device", "hac_encoder_set_profiling", "hac_encoder_profile_drain"):
+        getattr(L, name).restype = ctypes.c_int
     for name in ("hac_index_create", "hac_index_add", "hac_index_add_device", "hac_index_search",
                  "hac_index_search_device", "hac_index_search_keys_device", "hac_index_reset",
                  "hac_index_set_profiling", "hac_index_profile_drain", "hac_merge_keys_device",
@@ -57,7 +69,15 @@ EXPORTED_SYMBOLS = (
     "hac_index_add_device", "hac_index_search", "hac_index_search_device", "hac_index_search_keys_device",
     "hac_index_reset", "hac_index_ntotal", "hac_index_set_profiling", "hac_index_profile_drain", "hac_index_last_plan",
     "hac_merge_keys_device", "hac_keys_to_results_device",
+    "hac_encoder_create", "hac_encoder_destroy", "hac_encoder_set_weight", "hac_encoder_finalize", "hac_encoder_forward",
+    "hac_encoder_forward_device", "hac_encoder_set_profiling", "hac_encoder_profile_drain",
 )
+
+
+class EncoderConfig(ctypes.Structure):
+    _fields_ = [("n_layers", ctypes.c_int), ("hidden", ctypes.c_int), ("n_heads", ctypes.c_int), ("ffn", ctypes.c_int),
+                ("vocab", ctypes.c_int), ("max_pos", ctypes.c_int), ("type_vocab", ctypes.c_int), ("pad_token_id", ctypes.c_int),
+                ("ln_eps", ctypes.c_float)]
 
 
 def lib():

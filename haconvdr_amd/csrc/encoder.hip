@@ -1,0 +1,858 @@
+// ANCE / RoBERTa-base encoder forward for gfx950 (MI355X), behind hac_encoder_* (include/haconvdr.h).
+//
+// Reference path replaced: model(input_ids, attention_mask) — src/models.py:39-64
+// (ANCE.forward -> query_emb -> RobertaModel -> [:,0] -> embeddingHead -> norm), called at
+// src/test_HAConvDR_topiocqa.py:211 and gen_doc_embeddings.py:110.
+//
+// Design:
+//   * varlen: only the first len_b tokens of a sequence are computed (the reference's output is
+//     bit-identical whatever sits in masked positions); sequences are packed back to
+//     back, each padded to a multiple of 32 rows so no MFMA tile straddles two sequences.
+//   * GEMMs (QKV, attention-out, FFN up/down): bf16 operands, fp32 accumulate on
+//     v_mfma_f32_32x32x16_bf16, 128x128x64 tiles, register-staged double-buffered LDS with an
+//     XOR-swizzled image (conflict-free ds_read_b128), fused epilogues (bias, 1/8 query scale,
+//     V written transposed, exact-erf GELU, residual add).
+//   * the residual stream, LayerNorm, softmax and the final head stay fp32.
+//   * attention: one wave = 32 query rows of one (sequence, head); S^T = K.Q^T so the query sits
+//     on the lane, softmax statistics are lane-local; the S^T accumulator is converted in place
+//     into the A operand of P.V (no LDS); V comes pre-transposed from the QKV epilogue.
+#include "hac_common.h"
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace hac {
+namespace {
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+constexpr int H = 768;        // hidden size (RoBERTa-base / ANCE)
+constexpr int NH = 12;        // heads
+constexpr int DH = 64;        // head dim
+constexpr int FF = 3072;      // FFN inner size
+constexpr int SEQ_ALIGN = 32; // rows per sequence are padded to this
+constexpr int MT = 128, NTILE = 128, BK = 64;
+
+// ------------------------------------------------------------------ small helpers
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------ sequence bookkeeping
+struct SeqInfo {
+    int *lens;    // [B] valid tokens
+    int *len32;   // [B] rows occupied (multiple of 32)
+    int *off;     // [B+1] first packed row of each sequence; off[B] = total rows
+    int *pos;     // [B][L] position ids (HF rule), valid for t < len
+    int *err;     // [1] != 0 if some mask is not a prefix mask / empty
+};
+
+// one workgroup per sequence: len = sum(mask), prefix check, HF position ids
+//   pos = cumsum(id != pad) * (id != pad) + pad     (pad = 1)
+template <typename IT>
+__global__ __launch_bounds__(512) void seq_prep_kernel(const IT *__restrict__ ids, const IT *__restrict__ mask, int L, SeqInfo s,
+                                                       int pad_id) {
+    __shared__ int wsum[8];
+    __shared__ int wlen[8];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int t = tid;
+    int m = 0, np = 0;
+    if (t < L) {
+        m = mask[(size_t)b * L + t] != 0;
+        np = ids[(size_t)b * L + t] != (IT)pad_id;
+    }
+    // block reductions / scans over 512 threads (8 waves)
+    int mlen = m;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mlen += __shfl_xor(mlen, o);
+    int sc = np;  // inclusive scan within the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int v = __shfl_up(sc, o);
+        if (lane >= o) sc += v;
+    }
+    if (lane == 63) wsum[w] = sc;
+    if (lane == 0) wlen[w] = mlen;
+    __syncthreads();
+    int base = 0, len = 0;
+    for (int i = 0; i < 8; ++i) {
+        if (i < w) base += wsum[i];
+        len += wlen[i];
+    }
+    const int cum = sc + base;
+    if (t < L) {
+        s.pos[(size_t)b * L + t] = np ? cum + pad_id : pad_id;
+        if ((m != 0) != (t < len)) atomicOr(s.err, 1);  // not a prefix mask
+    }
+    if (tid == 0) {
+        if (len <= 0) atomicOr(s.err, 2);
+        s.lens[b] = len;
+        s.len32[b] = (len + SEQ_ALIGN - 1) / SEQ_ALIGN * SEQ_ALIGN;
+    }
+}
+
+__global__ void seq_offsets_kernel(SeqInfo s, int B) {
+    // B is small (<= a few thousand): one thread does the exclusive scan
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int acc = 0;
+        for (int b = 0; b < B; ++b) {
+            s.off[b] = acc;
+            acc += s.len32[b];
+        }
+        s.off[B] = acc;
+    }
+}
+
+// ------------------------------------------------------------------ LayerNorm over 768 (one wave per row)
+__device__ __forceinline__ void ln768_store(const float (&v)[12], const float *__restrict__ gamma, const float *__restrict__ beta,
+                                            float eps, int lane, float *__restrict__ out_f32, bf16 *__restrict__ out_bf) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s += v[i];
+    const float mean = wave_sum(s) * (1.0f / H);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const float d = v[i] - mean;
+        q += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / H) + eps);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = i * 256 + lane * 4;
+        const f4v g = *reinterpret_cast<const f4v *>(gamma + c);
+        const f4v bb = *reinterpret_cast<const f4v *>(beta + c);
+        f4v o;
+        o.x = (v[i * 4 + 0] - mean) * rstd * g.x + bb.x;
+        o.y = (v[i * 4 + 1] - mean) * rstd * g.y + bb.y;
+        o.z = (v[i * 4 + 2] - mean) * rstd * g.z + bb.z;
+        o.w = (v[i * 4 + 3] - mean) * rstd * g.w + bb.w;
+        if (out_f32) *reinterpret_cast<f4v *>(out_f32 + c) = o;
+        if (out_bf) {
+            bf16x4 ob;
+            ob.x = (bf16)o.x;
+            ob.y = (bf16)o.y;
+            ob.z = (bf16)o.z;
+            ob.w = (bf16)o.w;
+            *reinterpret_cast<bf16x4 *>(out_bf + c) = ob;
+        }
+    }
+}
+
+// K1: LN(word[id] + pos[pos_id] + type[0]) -> packed rows; dead rows (len <= t < len32) are zeroed
+template <typename IT>
+__global__ __launch_bounds__(256) void embed_ln_kernel(const IT *__restrict__ ids, int L, SeqInfo s, const float *__restrict__ word,
+                                                       const float *__restrict__ posw, const float *__restrict__ typew,
+                                                       const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                                       float *__restrict__ x_f32, bf16 *__restrict__ x_bf) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    if (t >= s.len32[b]) return;
+    const size_t row = (size_t)s.off[b] + t;
+    float v[12];
+    if (t < s.lens[b]) {
+        const long id = (long)ids[(size_t)b * L + t];
+        const int p = s.pos[(size_t)b * L + t];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int c = i * 256 + lane * 4;
+            const f4v a = *reinterpret_cast<const f4v *>(word + id * H + c);
+            const f4v pp = *reinterpret_cast<const f4v *>(posw + (size_t)p * H + c);
+            const f4v ty = *reinterpret_cast<const f4v *>(typew + c);
+            // same association as the reference: (inputs_embeds + token_type) + position
+            v[i * 4 + 0] = (a.x + ty.x) + pp.x;
+            v[i * 4 + 1] = (a.y + ty.y) + pp.y;
+            v[i * 4 + 2] = (a.z + ty.z) + pp.z;
+            v[i * 4 + 3] = (a.w + ty.w) + pp.w;
+        }
+        ln768_store(v, gamma, beta, eps, lane, x_f32 + row * H, x_bf + row * H);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int c = i * 256 + lane * 4;
+            *reinterpret_cast<f4v *>(x_f32 + row * H + c) = (f4v){0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<bf16x4 *>(x_bf + row * H + c) = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+        }
+    }
+}
+
+// K4/K6 tail: x = LN(y) for every packed row (y already holds dense + bias + residual)
+__global__ __launch_bounds__(256) void ln_rows_kernel(const float *__restrict__ y, const int *__restrict__ total_rows,
+                                                      const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                                      float *__restrict__ x_f32, bf16 *__restrict__ x_bf) {
+    const int lane = threadIdx.x & 63;
+    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (size_t)*total_rows) return;
+    float v[12];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const f4v a = *reinterpret_cast<const f4v *>(y + row * H + i * 256 + lane * 4);
+        v[i * 4 + 0] = a.x;
+        v[i * 4 + 1] = a.y;
+        v[i * 4 + 2] = a.z;
+        v[i * 4 + 3] = a.w;
+    }
+    ln768_store(v, gamma, beta, eps, lane, x_f32 + row * H, x_bf + row * H);
+}
+
+// ------------------------------------------------------------------ bf16 GEMM  C = A[M,K] . W[N,K]^T  (+ fused epilogue)
+enum { EPI_QKV = 0, EPI_RESID = 1, EPI_GELU = 2 };
+
+struct GemmArgs {
+    const bf16 *A;        // [Mp][K] row-major, Mp multiple of 128
+    const bf16 *W;        // [N][K] row-major (torch Linear weight)
+    const float *bias;    // [N]
+    int N, K;
+    const int *total_rows;  // device: rows in use; tiles starting beyond it exit
+    // epilogue outputs
+    bf16 *q, *k, *vt;     // EPI_QKV: q,k [Mp][768]; vt [768][ldvt]
+    long ldvt;
+    const float *resid;   // EPI_RESID: [Mp][768] fp32
+    float *y;             // EPI_RESID: [Mp][768] fp32
+    bf16 *h;              // EPI_GELU: [Mp][N] bf16
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
+    // LDS: two stages of {A tile 128x64, W tile 128x64} bf16; 16-byte chunk c of row r lives at
+    // r*128 + ((c ^ (r & 7)) << 4)   (XOR swizzle: the 8 rows of a ds_read_b128 lane group hit 8 distinct slots)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.y * MT, n0 = blockIdx.x * NTILE;
+    if (m0 >= *g.total_rows) return;
+    const int K = g.K, KT = K / BK;
+    const int wm = w >> 1, wn = w & 1;
+    const int r = lane & 31, hh = lane >> 5;
+
+    typedef const __attribute__((address_space(1))) f4v *gptr;
+    // staging: 1024 16-byte chunks per operand tile, 4 per thread
+    gptr ga[4], gw[4];
+    int lds_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = tid + i * 256;
+        const int row = ch >> 3, c = ch & 7;
+        ga[i] = (gptr)(g.A + (size_t)(m0 + row) * K + c * 8);
+        gw[i] = (gptr)(g.W + (size_t)(n0 + row) * K + c * 8);
+        lds_off[i] = row * 128 + ((c ^ (row & 7)) << 4);
+    }
+    f4v ra[4], rw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ra[i] = ga[i][0];
+        rw[i] = gw[i][0];
+    }
+    unsigned char *As = smem, *Ws = smem + 2 * MT * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<f4v *>(As + lds_off[i]) = ra[i];
+        *reinterpret_cast<f4v *>(Ws + lds_off[i]) = rw[i];
+    }
+    __syncthreads();
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    // fragment row offsets (bytes) inside a stage
+    int arow[2], wrow[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        arow[t] = wm * 64 + t * 32 + r;
+        wrow[t] = wn * 64 + t * 32 + r;
+    }
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ra[i] = ga[i][(size_t)(kt + 1) * (BK / 8)];
+                rw[i] = gw[i][(size_t)(kt + 1) * (BK / 8)];
+            }
+        }
+        const unsigned char *Ac = As + cur * (MT * 128), *Wc = Ws + cur * (NTILE * 128);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int c = ks * 2 + hh;
+            bf16x8 af[2], wf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                af[t] = *reinterpret_cast<const bf16x8 *>(Ac + arow[t] * 128 + ((c ^ (arow[t] & 7)) << 4));
+                wf[t] = *reinterpret_cast<const bf16x8 *>(Wc + wrow[t] * 128 + ((c ^ (wrow[t] & 7)) << 4));
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], wf[b], acc[a][b], 0, 0, 0);
+        }
+        if (kt + 1 < KT) {
+            unsigned char *An = As + (cur ^ 1) * (MT * 128), *Wn = Ws + (cur ^ 1) * (NTILE * 128);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<f4v *>(An + lds_off[i]) = ra[i];
+                *reinterpret_cast<f4v *>(Wn + lds_off[i]) = rw[i];
+            }
+        }
+        __syncthreads();
+    }
+
+    // epilogue.  acc[a][b][e]: n = n0 + wn*64 + b*32 + r ; m = m0 + wm*64 + a*32 + (e&3) + 8*(e>>2) + 4*hh
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int n = n0 + wn * 64 + b * 32 + r;
+        const float bias = g.bias[n];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int mb = m0 + wm * 64 + a * 32 + 4 * hh;
+            if constexpr (EPI == EPI_QKV) {
+                if (n < 2 * H) {
+                    bf16 *dst = n < H ? g.q : g.k;
+                    const int nn = n < H ? n : n - H;
+                    const float sc = n < H ? 0.125f : 1.0f;  // 1/sqrt(64) folded into Q (exact: power of two)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int m = mb + (e & 3) + 8 * (e >> 2);
+                        dst[(size_t)m * H + nn] = (bf16)((acc[a][b][e] + bias) * sc);
+                    }
+                } else {
+                    bf16 *dst = g.vt + (size_t)(n - 2 * H) * g.ldvt;  // V^T: 4 consecutive tokens per store
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) {
+                        bf16x4 o;
+                        o.x = (bf16)(acc[a][b][e4 * 4 + 0] + bias);
+                        o.y = (bf16)(acc[a][b][e4 * 4 + 1] + bias);
+                        o.z = (bf16)(acc[a][b][e4 * 4 + 2] + bias);
+                        o.w = (bf16)(acc[a][b][e4 * 4 + 3] + bias);
+                        *reinterpret_cast<bf16x4 *>(dst + mb + 8 * e4) = o;
+                    }
+                }
+            } else if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const size_t m = mb + (e & 3) + 8 * (e >> 2);
+                    g.y[m * H + n] = acc[a][b][e] + bias + g.resid[m * H + n];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const size_t m = mb + (e & 3) + 8 * (e >> 2);
+                    g.h[m * g.N + n] = (bf16)gelu_erf(acc[a][b][e] + bias);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ attention (one wave = 32 query rows of one (seq, head))
+struct AttnArgs {
+    const bf16 *q, *k, *vt;  // q (pre-scaled by 1/8), k: [Mp][768]; vt: [768][ldvt]
+    long ldvt;
+    bf16 *ctx;               // [Mp][768]
+    SeqInfo s;
+};
+
+__global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int b = blockIdx.z, head = blockIdx.y;
+    const int qb = blockIdx.x * 4 + w;
+    const int len32 = a.s.len32[b];
+    if (qb * 32 >= len32) return;  // no barriers below: whole waves may leave
+    const int len = a.s.lens[b];
+    const size_t base = (size_t)a.s.off[b];
+    const int r = lane & 31, hh = lane >> 5;
+    const int nkb = len32 >> 5;
+
+    // Q^T fragments (B operand of S^T = K.Q^T): lane (q = r, half hh) holds q[16*ks + 8*hh .. +8)
+    bf16x8 qf[4];
+    const bf16 *qrow = a.q + (base + qb * 32 + r) * H + head * DH + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8 *>(qrow + ks * 16);
+    const bf16 *kbase = a.k + (base + r) * H + head * DH + 8 * hh;
+
+    // pass 1: row maxima.  S^T tile: lane column = query r, register e <-> key (e&3) + 8*(e>>2) + 4*hh
+    float mx = -INFINITY;
+    for (int kb = 0; kb < nkb; ++kb) {
+        f32x16 s;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = 0.f;
+        const bf16 *kp = kbase + (size_t)kb * 32 * H;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(kp + ks * 16);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+        }
+        const int k0 = kb * 32 + 4 * hh;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int key = k0 + (e & 3) + 8 * (e >> 2);
+            if (key < len) mx = fmaxf(mx, s[e]);
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+
+    // pass 2: P = exp(S - max), l = sum P, O = P.V
+    float lsum = 0.f;
+    f32x16 o[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[t][e] = 0.f;
+    const float L2E = 1.44269504088896341f;
+    const float mxs = mx * L2E;
+    const bf16 *vbase = a.vt + (size_t)(head * DH + r) * a.ldvt + base + 4 * hh;
+    for (int kb = 0; kb < nkb; ++kb) {
+        f32x16 s;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = 0.f;
+        const bf16 *kp = kbase + (size_t)kb * 32 * H;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(kp + ks * 16);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+        }
+        const int k0 = kb * 32 + 4 * hh;
+        bf16x8 pf[2];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int key = k0 + (e & 3) + 8 * (e >> 2);
+            const float p = key < len ? exp2f(s[e] * L2E - mxs) : 0.f;
+            lsum += p;
+            pf[e >> 3][e & 7] = (bf16)p;
+        }
+        // P (registers 8s..8s+7 of the S^T accumulator) is the A operand of k-step s; slot j of half hh is
+        // key 16s + 8(j>>2) + 4hh + (j&3): V^T fragments are fetched in exactly that key order.
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const bf16 *vp = vbase + (size_t)(t * 32) * a.ldvt + kb * 32;
+#pragma unroll
+            for (int sidx = 0; sidx < 2; ++sidx) {
+                const bf16x4 v0 = *reinterpret_cast<const bf16x4 *>(vp + 16 * sidx);
+                const bf16x4 v1 = *reinterpret_cast<const bf16x4 *>(vp + 16 * sidx + 8);
+                bf16x8 vf;
+                vf[0] = v0.x; vf[1] = v0.y; vf[2] = v0.z; vf[3] = v0.w;
+                vf[4] = v1.x; vf[5] = v1.y; vf[6] = v1.z; vf[7] = v1.w;
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[sidx], vf, o[t], 0, 0, 0);
+            }
+        }
+    }
+    lsum += __shfl_xor(lsum, 32);
+    const float inv = 1.0f / lsum;  // lane r holds 1/l of query r (both halves)
+    // O tile t: lane column = d = 32t + r, register e <-> query row (e&3) + 8*(e>>2) + 4*hh
+    bf16 *crow = a.ctx + (base + qb * 32) * H + head * DH + r;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int qr = (e & 3) + 8 * (e >> 2) + 4 * hh;
+        const float sc = __shfl(inv, qr);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) crow[(size_t)qr * H + 32 * t] = (bf16)(o[t][e] * sc);
+    }
+}
+
+// ------------------------------------------------------------------ ANCE head: out[b] = LN(W_h . x[off[b]] + b_h)   (fp32)
+__global__ __launch_bounds__(256) void cls_head_kernel(const float *__restrict__ x, SeqInfo s, const float *__restrict__ Wh,
+                                                       const float *__restrict__ bh, const float *__restrict__ gamma,
+                                                       const float *__restrict__ beta, float eps, float *__restrict__ out) {
+    __shared__ float xs[H];
+    __shared__ float es[H];
+    __shared__ float red[8];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float *xr = x + (size_t)s.off[b] * H;
+    for (int i = tid; i < H; i += 256) xs[i] = xr[i];
+    __syncthreads();
+    const bool bad = *s.err != 0;
+    // each wave computes 192 outputs; a wave reads one weight row at a time (coalesced) and reduces
+    for (int n = w; n < H; n += 4) {
+        const float *wr = Wh + (size_t)n * H;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) acc = fmaf(wr[lane + 64 * i], xs[lane + 64 * i], acc);
+        acc = wave_sum(acc);
+        if (lane == 0) es[n] = acc + bh[n];
+    }
+    __syncthreads();
+    float sum = 0.f;
+    for (int i = tid; i < H; i += 256) sum += es[i];
+    sum = wave_sum(sum);
+    if (lane == 0) red[w] = sum;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) * (1.0f / H);
+    float q = 0.f;
+    for (int i = tid; i < H; i += 256) {
+        const float d = es[i] - mean;
+        q += d * d;
+    }
+    q = wave_sum(q);
+    __syncthreads();
+    if (lane == 0) red[4 + w] = q;
+    __syncthreads();
+    const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) * (1.0f / H) + eps);
+    for (int i = tid; i < H; i += 256) {
+        const float v = (es[i] - mean) * rstd * gamma[i] + beta[i];
+        out[(size_t)b * H + i] = bad ? NAN : v;  // unsupported (non-prefix / empty) mask: fail loudly, never guess
+    }
+}
+
+__global__ void f32_to_bf16_kernel(const float *__restrict__ src, bf16 *__restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (bf16)src[i];
+}
+
+}  // namespace
+}  // namespace hac
+
+// =============================================================================
+// host side + C ABI
+// =============================================================================
+using namespace hac;
+
+namespace {
+
+struct LayerW {
+    bf16 *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;
+    float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
+    float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr;
+};
+
+}  // namespace
+
+struct hac_encoder {
+    hac_encoder_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::map<std::string, float *> raw;       // device fp32 copies of the checkpoint tensors
+    std::map<std::string, size_t> raw_count;
+    std::vector<LayerW> layers;
+    float *word = nullptr, *posw = nullptr, *typew = nullptr, *embg = nullptr, *embb = nullptr;
+    float *wh = nullptr, *bh = nullptr, *ng = nullptr, *nb = nullptr;
+    bool finalized = false;
+    // workspace
+    GrowBuf ws_x, ws_xb, ws_q, ws_k, ws_vt, ws_ctx, ws_y, ws_h, ws_seq, ws_ids, ws_mask, ws_out;
+    void *h_pin = nullptr;
+    size_t h_pin_bytes = 0;
+    // profiling (bench): events around the layer stack of each forward
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    long max_tokens = 131072;  // packed rows per sub-batch
+};
+
+namespace {
+
+int enc_fail_missing(const std::string &name) { return fail(HAC_ERR_INVALID, "encoder weight '%s' was never set", name.c_str()); }
+
+int get_raw(hac_encoder *e, const std::string &name, size_t count, float **out) {
+    auto it = e->raw.find(name);
+    if (it == e->raw.end()) return enc_fail_missing(name);
+    if (e->raw_count[name] != count) return fail(HAC_ERR_INVALID, "encoder weight '%s' has %zu elements, expected %zu", name.c_str(), e->raw_count[name], count);
+    *out = it->second;
+    return HAC_OK;
+}
+
+int to_bf16(hac_encoder *e, const float *src, size_t n, bf16 **out) {
+    HAC_HIP(hipMalloc((void **)out, n * sizeof(bf16)));
+    f32_to_bf16_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream>>>(src, *out, n);
+    HAC_HIP(hipGetLastError());
+    return HAC_OK;
+}
+
+template <typename IT>
+int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, float *out_dev, hipStream_t st) {
+    const hac_encoder_config &c = e->cfg;
+    const int L32 = (L + SEQ_ALIGN - 1) / SEQ_ALIGN * SEQ_ALIGN;
+    const long rows_max = (long)B * L32;
+    const long Mp = (rows_max + MT - 1) / MT * MT;
+    HAC_TRY(e->ws_x.reserve((size_t)Mp * H * 4));
+    HAC_TRY(e->ws_y.reserve((size_t)Mp * H * 4));
+    HAC_TRY(e->ws_xb.reserve((size_t)Mp * H * 2));
+    HAC_TRY(e->ws_q.reserve((size_t)Mp * H * 2));
+    HAC_TRY(e->ws_k.reserve((size_t)(Mp + 64) * H * 2));
+    HAC_TRY(e->ws_vt.reserve((size_t)H * (Mp + 64) * 2));
+    HAC_TRY(e->ws_ctx.reserve((size_t)Mp * H * 2));
+    HAC_TRY(e->ws_h.reserve((size_t)Mp * FF * 2));
+    const size_t seq_ints = (size_t)3 * B + 2 + 2 + (size_t)B * L;
+    HAC_TRY(e->ws_seq.reserve(seq_ints * 4));
+    SeqInfo s;
+    int *p = (int *)e->ws_seq.p;
+    s.lens = p;
+    s.len32 = p + B;
+    s.off = p + 2 * B;          // B+1 entries
+    s.err = p + 3 * B + 2;
+    s.pos = p + 3 * B + 4;
+    HAC_HIP(hipMemsetAsync(s.err, 0, 4, st));
+    seq_prep_kernel<IT><<<dim3(B), dim3(512), 0, st>>>(ids, mask, L, s, c.pad_token_id);
+    seq_offsets_kernel<<<dim3(1), dim3(64), 0, st>>>(s, B);
+    float *x = (float *)e->ws_x.p, *y = (float *)e->ws_y.p;
+    bf16 *xb = (bf16 *)e->ws_xb.p, *q = (bf16 *)e->ws_q.p, *k = (bf16 *)e->ws_k.p, *vt = (bf16 *)e->ws_vt.p;
+    bf16 *ctx = (bf16 *)e->ws_ctx.p, *h = (bf16 *)e->ws_h.p;
+    const long ldvt = Mp + 64;
+    // dead tail rows of the last M tile feed the GEMMs: keep them finite
+    HAC_HIP(hipMemsetAsync(xb, 0, (size_t)Mp * H * 2, st));
+    HAC_HIP(hipMemsetAsync(x, 0, (size_t)Mp * H * 4, st));
+    embed_ln_kernel<IT><<<dim3(L32 / 4, B), dim3(256), 0, st>>>(ids, L, s, e->word, e->posw, e->typew, e->embg, e->embb, c.ln_eps, x, xb);
+    HAC_HIP(hipGetLastError());
+    const int *total = s.off + B;
+    const unsigned mt = (unsigned)(Mp / MT);
+    const size_t lds = 4 * MT * 128;
+    if (e->profiling) {
+        if (e->ev_used == e->ev_pool.size()) {
+            hipEvent_t a0, a1;
+            HAC_HIP(hipEventCreate(&a0));
+            HAC_HIP(hipEventCreate(&a1));
+            e->ev_pool.emplace_back(a0, a1);
+        }
+        HAC_HIP(hipEventRecord(e->ev_pool[e->ev_used].first, st));
+    }
+    for (int li = 0; li < c.n_layers; ++li) {
+        const LayerW &w = e->layers[li];
+        GemmArgs g{};
+        g.total_rows = total;
+        // QKV
+        g.A = xb; g.W = w.wqkv; g.bias = w.bqkv; g.N = 3 * H; g.K = H; g.q = q; g.k = k; g.vt = vt; g.ldvt = ldvt;
+        gemm_bf16_nt_kernel<EPI_QKV><<<dim3(3 * H / NTILE, mt), dim3(256), lds, st>>>(g);
+        AttnArgs a{q, k, vt, ldvt, ctx, s};
+        attention_kernel<<<dim3((L32 / 32 + 3) / 4, NH, B), dim3(256), 0, st>>>(a);
+        // attention output projection + residual, LN
+        g.A = ctx; g.W = w.wo; g.bias = w.bo; g.N = H; g.K = H; g.resid = x; g.y = y;
+        gemm_bf16_nt_kernel<EPI_RESID><<<dim3(H / NTILE, mt), dim3(256), lds, st>>>(g);
+        ln_rows_kernel<<<dim3((unsigned)(Mp / 4)), dim3(256), 0, st>>>(y, total, w.ln1g, w.ln1b, c.ln_eps, x, xb);
+        // FFN
+        g.A = xb; g.W = w.w1; g.bias = w.b1; g.N = FF; g.K = H; g.h = h;
+        gemm_bf16_nt_kernel<EPI_GELU><<<dim3(FF / NTILE, mt), dim3(256), lds, st>>>(g);
+        g.A = h; g.W = w.w2; g.bias = w.b2; g.N = H; g.K = FF; g.resid = x; g.y = y;
+        gemm_bf16_nt_kernel<EPI_RESID><<<dim3(H / NTILE, mt), dim3(256), lds, st>>>(g);
+        ln_rows_kernel<<<dim3((unsigned)(Mp / 4)), dim3(256), 0, st>>>(y, total, w.ln2g, w.ln2b, c.ln_eps, x, xb);
+        HAC_HIP(hipGetLastError());
+    }
+    if (e->profiling) {
+        HAC_HIP(hipEventRecord(e->ev_pool[e->ev_used].second, st));
+        ++e->ev_used;
+    }
+    cls_head_kernel<<<dim3(B), dim3(256), 0, st>>>(x, s, e->wh, e->bh, e->ng, e->nb, 1e-5f, out_dev);
+    HAC_HIP(hipGetLastError());
+    return HAC_OK;
+}
+
+template <typename IT>
+int forward_batched(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, float *out_dev, hipStream_t st) {
+    const int L32 = (L + SEQ_ALIGN - 1) / SEQ_ALIGN * SEQ_ALIGN;
+    int per = (int)std::max<long>(1, e->max_tokens / L32);
+    for (int b0 = 0; b0 < B; b0 += per) {
+        const int nb = std::min(per, B - b0);
+        HAC_TRY(run_forward<IT>(e, ids + (size_t)b0 * L, mask + (size_t)b0 * L, nb, L, out_dev + (size_t)b0 * H, st));
+    }
+    return HAC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hac_encoder_create(const hac_encoder_config *cfg, int device, hac_encoder **out) {
+    if (!out || !cfg) return fail(HAC_ERR_INVALID, "hac_encoder_create: null argument");
+    *out = nullptr;
+    if (cfg->hidden != H || cfg->n_heads != NH || cfg->ffn != FF)
+        return fail(HAC_ERR_UNSUPPORTED, "only the RoBERTa-base geometry of ANCE is built (hidden 768, 12 heads, ffn 3072); got %d/%d/%d", cfg->hidden,
+                    cfg->n_heads, cfg->ffn);
+    if (cfg->n_layers < 1 || cfg->n_layers > 48 || cfg->vocab < 1 || cfg->max_pos < 3 || cfg->type_vocab < 1)
+        return fail(HAC_ERR_INVALID, "bad encoder config");
+    int n_visible = 0;
+    if (hipGetDeviceCount(&n_visible) != hipSuccess || n_visible <= 0)
+        return fail(HAC_ERR_HIP, "no HIP device visible: the haconvdr encoder has no CPU fallback");
+    if (device < 0 || device >= n_visible) return fail(HAC_ERR_INVALID, "device id %d out of range (visible: %d)", device, n_visible);
+    hac_encoder *e = new hac_encoder();
+    e->cfg = *cfg;
+    e->device = device;
+    DeviceGuard g(device);
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete e;
+        return fail(HAC_ERR_HIP, "hipStreamCreate failed");
+    }
+    (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    *out = e;
+    return HAC_OK;
+}
+
+void hac_encoder_destroy(hac_encoder *e) {
+    if (!e) return;
+    DeviceGuard g(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (auto &kv : e->raw) (void)hipFree(kv.second);
+    for (auto &l : e->layers)
+        for (bf16 *p : {l.wqkv, l.wo, l.w1, l.w2})
+            if (p) (void)hipFree(p);
+    for (auto &l : e->layers)
+        if (l.bqkv) (void)hipFree(l.bqkv);
+    for (GrowBuf *b : {&e->ws_x, &e->ws_xb, &e->ws_q, &e->ws_k, &e->ws_vt, &e->ws_ctx, &e->ws_y, &e->ws_h, &e->ws_seq, &e->ws_ids, &e->ws_mask, &e->ws_out})
+        b->release();
+    if (e->h_pin) (void)hipHostFree(e->h_pin);
+    for (auto &ev : e->ev_pool) {
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int hac_encoder_set_weight(hac_encoder *e, const char *name, const float *data, size_t count) {
+    if (!e || !name || !data || count == 0) return fail(HAC_ERR_INVALID, "set_weight: bad arguments");
+    DeviceGuard g(e->device);
+    std::string key(name);
+    auto it = e->raw.find(key);
+    if (it != e->raw.end()) {
+        (void)hipFree(it->second);
+        e->raw.erase(it);
+    }
+    float *d = nullptr;
+    HAC_HIP(hipMalloc((void **)&d, count * 4));
+    HAC_HIP(hipMemcpy(d, data, count * 4, hipMemcpyHostToDevice));
+    e->raw[key] = d;
+    e->raw_count[key] = count;
+    e->finalized = false;
+    return HAC_OK;
+}
+
+int hac_encoder_finalize(hac_encoder *e) {
+    if (!e) return fail(HAC_ERR_INVALID, "null encoder");
+    DeviceGuard g(e->device);
+    const hac_encoder_config &c = e->cfg;
+    const std::string p = "roberta.embeddings.";
+    HAC_TRY(get_raw(e, p + "word_embeddings.weight", (size_t)c.vocab * H, &e->word));
+    HAC_TRY(get_raw(e, p + "position_embeddings.weight", (size_t)c.max_pos * H, &e->posw));
+    HAC_TRY(get_raw(e, p + "token_type_embeddings.weight", (size_t)c.type_vocab * H, &e->typew));
+    HAC_TRY(get_raw(e, p + "LayerNorm.weight", H, &e->embg));
+    HAC_TRY(get_raw(e, p + "LayerNorm.bias", H, &e->embb));
+    HAC_TRY(get_raw(e, "embeddingHead.weight", (size_t)H * H, &e->wh));
+    HAC_TRY(get_raw(e, "embeddingHead.bias", H, &e->bh));
+    HAC_TRY(get_raw(e, "norm.weight", H, &e->ng));
+    HAC_TRY(get_raw(e, "norm.bias", H, &e->nb));
+    for (auto &l : e->layers) {
+        for (bf16 *pp : {l.wqkv, l.wo, l.w1, l.w2})
+            if (pp) (void)hipFree(pp);
+        if (l.bqkv) (void)hipFree(l.bqkv);
+    }
+    e->layers.assign(c.n_layers, LayerW());
+    for (int i = 0; i < c.n_layers; ++i) {
+        const std::string q = "roberta.encoder.layer." + std::to_string(i) + ".";
+        LayerW &l = e->layers[i];
+        float *wq, *wk, *wv, *bq, *bk, *bv, *t;
+        HAC_TRY(get_raw(e, q + "attention.self.query.weight", (size_t)H * H, &wq));
+        HAC_TRY(get_raw(e, q + "attention.self.key.weight", (size_t)H * H, &wk));
+        HAC_TRY(get_raw(e, q + "attention.self.value.weight", (size_t)H * H, &wv));
+        HAC_TRY(get_raw(e, q + "attention.self.query.bias", H, &bq));
+        HAC_TRY(get_raw(e, q + "attention.self.key.bias", H, &bk));
+        HAC_TRY(get_raw(e, q + "attention.self.value.bias", H, &bv));
+        HAC_HIP(hipMalloc((void **)&l.wqkv, (size_t)3 * H * H * sizeof(bf16)));
+        HAC_HIP(hipMalloc((void **)&l.bqkv, (size_t)3 * H * 4));
+        const float *ws[3] = {wq, wk, wv};
+        const float *bs[3] = {bq, bk, bv};
+        for (int j = 0; j < 3; ++j) {
+            f32_to_bf16_kernel<<<dim3((unsigned)(((size_t)H * H + 255) / 256)), dim3(256), 0, e->stream>>>(ws[j], l.wqkv + (size_t)j * H * H, (size_t)H * H);
+            HAC_HIP(hipMemcpyAsync(l.bqkv + j * H, bs[j], H * 4, hipMemcpyDeviceToDevice, e->stream));
+        }
+        HAC_TRY(get_raw(e, q + "attention.output.dense.weight", (size_t)H * H, &t));
+        HAC_TRY(to_bf16(e, t, (size_t)H * H, &l.wo));
+        HAC_TRY(get_raw(e, q + "attention.output.dense.bias", H, &l.bo));
+        HAC_TRY(get_raw(e, q + "attention.output.LayerNorm.weight", H, &l.ln1g));
+        HAC_TRY(get_raw(e, q + "attention.output.LayerNorm.bias", H, &l.ln1b));
+        HAC_TRY(get_raw(e, q + "intermediate.dense.weight", (size_t)FF * H, &t));
+        HAC_TRY(to_bf16(e, t, (size_t)FF * H, &l.w1));
+        HAC_TRY(get_raw(e, q + "intermediate.dense.bias", FF, &l.b1));
+        HAC_TRY(get_raw(e, q + "output.dense.weight", (size_t)H * FF, &t));
+        HAC_TRY(to_bf16(e, t, (size_t)H * FF, &l.w2));
+        HAC_TRY(get_raw(e, q + "output.dense.bias", H, &l.b2));
+        HAC_TRY(get_raw(e, q + "output.LayerNorm.weight", H, &l.ln2g));
+        HAC_TRY(get_raw(e, q + "output.LayerNorm.bias", H, &l.ln2b));
+    }
+    HAC_HIP(hipStreamSynchronize(e->stream));
+    e->finalized = true;
+    return HAC_OK;
+}
+
+int hac_encoder_forward_device(hac_encoder *e, const void *ids_dev, const void *mask_dev, int elem_bytes, int B, int L,
+                               float *out_dev, void *hip_stream) {
+    if (!e) return fail(HAC_ERR_INVALID, "null encoder");
+    if (!e->finalized) return fail(HAC_ERR_INVALID, "encoder weights not finalized (hac_encoder_finalize)");
+    if (B < 0 || L < 1 || L > 512 || L + 2 > e->cfg.max_pos || (B > 0 && (!ids_dev || !mask_dev || !out_dev)))
+        return fail(HAC_ERR_INVALID, "forward: bad arguments (B=%d, L=%d; L must be in [1, min(512, max_pos-2)])", B, L);
+    if (elem_bytes != 4 && elem_bytes != 8) return fail(HAC_ERR_INVALID, "forward: ids/mask must be int32 or int64");
+    if (B == 0) return HAC_OK;
+    DeviceGuard g(e->device);
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (elem_bytes == 8) return forward_batched<long long>(e, (const long long *)ids_dev, (const long long *)mask_dev, B, L, out_dev, st);
+    return forward_batched<int>(e, (const int *)ids_dev, (const int *)mask_dev, B, L, out_dev, st);
+}
+
+int hac_encoder_forward(hac_encoder *e, const int32_t *ids, const int32_t *mask, int B, int L, float *out) {
+    if (!e) return fail(HAC_ERR_INVALID, "null encoder");
+    if (B < 0 || (B > 0 && (!ids || !mask || !out))) return fail(HAC_ERR_INVALID, "forward: bad arguments");
+    if (B == 0) return HAC_OK;
+    DeviceGuard g(e->device);
+    const size_t n = (size_t)B * L;
+    HAC_TRY(e->ws_ids.reserve(n * 4));
+    HAC_TRY(e->ws_mask.reserve(n * 4));
+    HAC_TRY(e->ws_out.reserve((size_t)B * H * 4));
+    const size_t need = std::max(n * 8, (size_t)B * H * 4);
+    if (e->h_pin_bytes < need) {
+        if (e->h_pin) (void)hipHostFree(e->h_pin);
+        e->h_pin = nullptr;
+        e->h_pin_bytes = 0;
+        hipError_t err = hipHostMalloc(&e->h_pin, need + need / 4, hipHostMallocDefault);
+        if (err != hipSuccess) return fail(HAC_ERR_OOM, "hipHostMalloc failed: %s", hipGetErrorString(err));
+        e->h_pin_bytes = need + need / 4;
+    }
+    HAC_HIP(hipStreamSynchronize(e->stream));
+    std::memcpy(e->h_pin, ids, n * 4);
+    std::memcpy((char *)e->h_pin + n * 4, mask, n * 4);
+    HAC_HIP(hipMemcpyAsync(e->ws_ids.p, e->h_pin, n * 4, hipMemcpyHostToDevice, e->stream));
+    HAC_HIP(hipMemcpyAsync(e->ws_mask.p, (char *)e->h_pin + n * 4, n * 4, hipMemcpyHostToDevice, e->stream));
+    HAC_TRY(hac_encoder_forward_device(e, e->ws_ids.p, e->ws_mask.p, 4, B, L, (float *)e->ws_out.p, e->stream));
+    HAC_HIP(hipStreamSynchronize(e->stream));  // the pinned buffer is reused for the result
+    HAC_HIP(hipMemcpyAsync(e->h_pin, e->ws_out.p, (size_t)B * H * 4, hipMemcpyDeviceToHost, e->stream));
+    HAC_HIP(hipStreamSynchronize(e->stream));
+    std::memcpy(out, e->h_pin, (size_t)B * H * 4);
+    for (size_t i = 0; i < (size_t)B * H; ++i)
+        if (out[i] != out[i]) return fail(HAC_ERR_INVALID, "forward: attention_mask must be a non-empty prefix mask (first len ones) for every sequence");
+    return HAC_OK;
+}
+
+int hac_encoder_set_profiling(hac_encoder *e, int enable) {
+    if (!e) return fail(HAC_ERR_INVALID, "null encoder");
+    e->profiling = enable != 0;
+    return HAC_OK;
+}
+
+int hac_encoder_profile_drain(hac_encoder *e, float *ms_out, int cap, int *n_out) {
+    if (!e || !n_out || (cap > 0 && !ms_out)) return fail(HAC_ERR_INVALID, "bad arguments");
+    DeviceGuard g(e->device);
+    int n = 0;
+    for (size_t i = 0; i < e->ev_used && n < cap; ++i, ++n) {
+        HAC_HIP(hipEventSynchronize(e->ev_pool[i].second));
+        HAC_HIP(hipEventElapsedTime(&ms_out[n], e->ev_pool[i].first, e->ev_pool[i].second));
+    }
+    e->ev_used = 0;
+    *n_out = n;
+    return HAC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,107 @@
+"""Encoder seam of the reference, host-side mirror.
+
+``ANCEEncoder`` is called exactly like the reference's module: ``model(input_ids,
+attention_mask)`` with integer tensors [B, L] (src/test_HAConvDR_topiocqa.py:211,
+gen_doc_embeddings.py:110) and returns a float32 tensor [B, 768] on the same device
+(= src/models.py:44).  Weights use the checkpoint's own key names (``roberta.*``,
+``embeddingHead.*``, ``norm.*``; ``classifier.*`` is ignored as in the reference's forward).
+All arithmetic runs in the gfx950 HIP kernels of libhaconvdr.so; there is no CPU fallback.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+class ANCEEncoder:
+    def __init__(self, n_layers=12, vocab=50265, max_pos=514, type_vocab=1, pad_token_id=1, ln_eps=1e-5, device=0):
+        self.device = int(device)
+        self.n_layers = int(n_layers)
+        cfg = _lib.EncoderConfig(self.n_layers, 768, 12, 3072, int(vocab), int(max_pos), int(type_vocab), int(pad_token_id), float(ln_eps))
+        self._h = ctypes.c_void_p()
+        _lib.check(_lib.lib().hac_encoder_create(ctypes.byref(cfg), self.device, ctypes.byref(self._h)))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().hac_encoder_destroy(h)
+            except Exception:
+                pass
+
+    # ---- weights -----------------------------------------------------------
+    def load_state_dict(self, sd):
+        """sd: name -> float32 array / torch tensor with the reference checkpoint's names."""
+        L = _lib.lib()
+        for name, v in sd.items():
+            if name.startswith("classifier.") or name.endswith("position_ids"):
+                continue                       # present in the checkpoint, unused by ANCE.forward (models.py:26)
+            a = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            _lib.check(L.hac_encoder_set_weight(self._h, name.encode(), a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), a.size))
+        _lib.check(L.hac_encoder_finalize(self._h))
+        return self
+
+    @classmethod
+    def from_state_dict(cls, sd, device=0, **kw):
+        n_layers = 1 + max(int(k.split(".")[3]) for k in sd if k.startswith("roberta.encoder.layer."))
+        vocab, _ = np.shape(sd["roberta.embeddings.word_embeddings.weight"])
+        max_pos, _ = np.shape(sd["roberta.embeddings.position_embeddings.weight"])
+        tv, _ = np.shape(sd["roberta.embeddings.token_type_embeddings.weight"])
+        return cls(n_layers=n_layers, vocab=vocab, max_pos=max_pos, type_vocab=tv, device=device, **kw).load_state_dict(sd)
+
+    @classmethod
+    def from_pretrained(cls, path, device=0):
+        """Checkpoint directory as ANCE.from_pretrained reads it (:170): pytorch_model.bin or model.safetensors."""
+        import os
+        import torch
+        st = os.path.join(path, "model.safetensors")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+            sd = load_file(st)
+        else:
+            sd = torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu")
+        return cls.from_state_dict({k: v.float() for k, v in sd.items()}, device=device)
+
+    # ---- forward -----------------------------------------------------------
+    def __call__(self, input_ids, attention_mask, wrap_pooler=False):
+        """model(input_ids, attention_mask) -> float32 [B, 768].  torch CUDA tensors stay on the GPU
+        (enqueued on the current stream); numpy / CPU inputs take the synchronous host path."""
+        import torch
+        if isinstance(input_ids, torch.Tensor) and input_ids.is_cuda:
+            ids = input_ids.contiguous()
+            mask = attention_mask.to(ids.dtype).contiguous()
+            if ids.dtype not in (torch.int32, torch.int64):
+                ids, mask = ids.long(), mask.long()
+            B, L = ids.shape
+            out = torch.empty((B, 768), dtype=torch.float32, device=ids.device)
+            st = torch.cuda.current_stream().cuda_stream
+            _lib.check(_lib.lib().hac_encoder_forward_device(self._h, ctypes.c_void_p(ids.data_ptr()), ctypes.c_void_p(mask.data_ptr()),
+                                                            ids.element_size(), B, L, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(st)))
+            return out
+        ids = np.ascontiguousarray(np.asarray(input_ids), dtype=np.int32)
+        mask = np.ascontiguousarray(np.asarray(attention_mask), dtype=np.int32)
+        B, L = ids.shape
+        out = np.empty((B, 768), np.float32)
+        i32p = ctypes.POINTER(ctypes.c_int32)
+        _lib.check(_lib.lib().hac_encoder_forward(self._h, ids.ctypes.data_as(i32p), mask.ctypes.data_as(i32p), B, L,
+                                                  out.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
+        return torch.from_numpy(out) if isinstance(input_ids, torch.Tensor) else out
+
+    forward = query_emb = doc_emb = __call__       # models.py:39-49,63-64
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        return self
+
+    def set_profiling(self, on=True):
+        _lib.check(_lib.lib().hac_encoder_set_profiling(self._h, int(bool(on))))
+
+    def profile_drain(self, cap=4096):
+        buf = (ctypes.c_float * cap)()
+        n = ctypes.c_int()
+        _lib.check(_lib.lib().hac_encoder_profile_drain(self._h, buf, cap, ctypes.byref(n)))
+        return [float(buf[i]) for i in range(n.value)]

@@ -115,6 +115,44 @@ int hac_keys_to_results_device(int device, const uint64_t *keys_dev, int64_t n_k
                                const int64_t *id_map_dev, float *D_dev, int64_t *I_dev,
                                void *hip_stream);
 
+/* ----------------------------------------------------------------- encoder */
+/* model(input_ids, attention_mask) -> float32 [B,768]: ANCE.forward, src/models.py:39-64
+ * (RobertaModel -> last_hidden_state[:,0] -> embeddingHead -> norm), called at
+ * src/test_HAConvDR_topiocqa.py:211 and gen_doc_embeddings.py:110.  RoBERTa-base geometry. */
+typedef struct hac_encoder hac_encoder;
+typedef struct {
+    int n_layers;      /* 12 for ANCE */
+    int hidden;        /* 768 */
+    int n_heads;       /* 12 */
+    int ffn;           /* 3072 */
+    int vocab;         /* 50265 */
+    int max_pos;       /* 514 */
+    int type_vocab;    /* 1 */
+    int pad_token_id;  /* 1: position ids are cumsum(id != pad)*(id != pad) + pad (HF RoBERTa) */
+    float ln_eps;      /* 1e-5 */
+} hac_encoder_config;
+
+int hac_encoder_create(const hac_encoder_config *cfg, int device, hac_encoder **out);
+void hac_encoder_destroy(hac_encoder *enc);
+/* One tensor of the checkpoint, by its state-dict name (ANCE.from_pretrained keys, :170):
+ * "roberta.embeddings.*", "roberta.encoder.layer.N.*", "embeddingHead.*", "norm.*"
+ * ("classifier.*" exists in the checkpoint but is unused by forward: do not pass it).
+ * data: host float32, copied before return. */
+int hac_encoder_set_weight(hac_encoder *enc, const char *name, const float *data, size_t count);
+/* Checks that every tensor is present and packs the GEMM weights to bf16. */
+int hac_encoder_finalize(hac_encoder *enc);
+/* ids, mask: host int32 [B, L]; mask must be a prefix mask (first len >= 1 ones) as both
+ * reference pipelines produce (gen_doc_embeddings.py:38-40, src/data.py:8-23); out: host float32
+ * [B, 768].  Synchronous. */
+int hac_encoder_forward(hac_encoder *enc, const int32_t *ids, const int32_t *mask, int B, int L, float *out);
+/* Device/stream variant: ids/mask device pointers of elem_bytes 4 (int32) or 8 (int64, what the
+ * reference passes); out_dev float32 [B,768].  A non-prefix mask yields NaN rows. */
+int hac_encoder_forward_device(hac_encoder *enc, const void *ids_dev, const void *mask_dev, int elem_bytes,
+                               int B, int L, float *out_dev, void *hip_stream);
+/* hipEvent pairs around the 12-layer stack of each forward (bench.py). */
+int hac_encoder_set_profiling(hac_encoder *enc, int enable);
+int hac_encoder_profile_drain(hac_encoder *enc, float *ms_out, int cap, int *n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,133 @@
+"""GPU parity tests of the ANCE encoder, THROUGH THE C ABI.  Bar (BASELINE.json north_star):
+embedding cosine within 1e-3 of the reference CPU path; the goldens are outputs of the
+reference's own models.ANCE (tests/golden/make_golden_encoder.py)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "encoder_*.npz")))
+COS_TOL = 1e-3          # the contract
+COS_EXPECT = 2e-4       # what bf16 GEMMs + fp32 residual/LN/softmax actually deliver (2e-5..1e-4)
+_SD, _ENC = {}, {}
+
+
+def state_dict(n_layers):
+    from haconvdr_amd import synth
+    if n_layers not in _SD:
+        _SD[n_layers] = synth.ance_state_dict(0xA11CE, n_layers)
+    return _SD[n_layers]
+
+
+def encoder(n_layers):
+    from haconvdr_amd.encoder import ANCEEncoder
+    if n_layers not in _ENC:
+        _ENC[n_layers] = ANCEEncoder.from_state_dict(state_dict(n_layers))
+    return _ENC[n_layers]
+
+
+def one_minus_cos(a, b):
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    return 1.0 - (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[8:-4] for p in GOLD])
+def test_encoder_vs_reference_golden(path):
+    g = np.load(path)
+    enc = encoder(int(g["n_layers"]))
+    out = enc(g["ids"].astype(np.int32), g["mask"].astype(np.int32))
+    ref = g["ref_out"]
+    assert out.shape == ref.shape and out.dtype == np.float32
+    d = one_minus_cos(out, ref)
+    assert np.all(d < COS_TOL), d
+    assert np.all(d < COS_EXPECT), d
+    # LayerNorm'd outputs of norm ~27.7: elementwise agreement too
+    assert np.abs(out - ref).max() < 0.25
+
+
+def test_encoder_vs_oracle_one_layer():
+    """1-layer model: errors cannot hide behind 12 layers of averaging."""
+    from haconvdr_amd import synth
+    from haconvdr_amd.encoder import ANCEEncoder
+    from oracle import ance_oracle
+    from tests.golden.make_golden_encoder import encoder_case_inputs
+    sd = synth.ance_state_dict(0xBEE, 1)
+    enc = ANCEEncoder.from_state_dict(sd)
+    ids, mask = encoder_case_inputs(99, [1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 300, 511, 512], 512)
+    out = enc(ids.astype(np.int32), mask.astype(np.int32))
+    ref = ance_oracle.ance_forward(sd, ids, mask)
+    d = one_minus_cos(out, ref)
+    assert np.all(d < 5e-5), d
+    assert np.abs(out - ref).max() < 0.1
+
+
+def test_torch_tensor_path_int64_and_pad_invariance():
+    """The reference hands int64 CUDA tensors; results must not depend on what sits in masked
+    positions (bit-identical in the reference) nor on the id dtype."""
+    import torch
+    g = np.load([p for p in GOLD if "l2_mixed" in p][0])
+    enc = encoder(2)
+    ids = torch.from_numpy(g["ids"].astype(np.int64)).cuda()
+    mask = torch.from_numpy(g["mask"].astype(np.int64)).cuda()
+    out64 = enc(ids, mask)
+    assert out64.is_cuda and out64.dtype == torch.float32 and tuple(out64.shape) == (8, 768)
+    out32 = enc(ids.int(), mask.int())
+    assert torch.equal(out64, out32)
+    junk = ids.clone()
+    junk[mask == 0] = 1
+    assert torch.equal(enc(junk, mask), out64)
+    host = enc(g["ids"].astype(np.int32), g["mask"].astype(np.int32))
+    np.testing.assert_array_equal(host, out64.cpu().numpy())
+
+
+def test_batch_composition_invariance():
+    """A sequence's embedding does not depend on its batch neighbours or its slot."""
+    g = np.load([p for p in GOLD if "l2_mixed" in p][0])
+    enc = encoder(2)
+    ids, mask = g["ids"].astype(np.int32), g["mask"].astype(np.int32)
+    full = enc(ids, mask)
+    perm = np.array([5, 0, 7, 2])
+    part = enc(ids[perm], mask[perm])
+    np.testing.assert_array_equal(part, full[perm])
+    np.testing.assert_array_equal(enc(ids[3:4, :128], mask[3:4, :128]), full[3:4])   # shorter padded length L
+
+
+def test_large_batch_subbatching():
+    """More rows than one sub-batch holds: same embeddings as the small batches."""
+    from haconvdr_amd import synth
+    enc = encoder(2)
+    ids, lens = synth.token_batch(31, 600, 384, min_len=8)
+    mask = (np.arange(384)[None, :] < lens[:, None]).astype(np.int32)
+    out = enc(ids, mask)
+    assert np.isfinite(out).all()
+    sel = [0, 17, 599]
+    np.testing.assert_array_equal(out[sel], enc(ids[sel], mask[sel]))
+
+
+def test_bad_masks_fail_loudly():
+    from haconvdr_amd._lib import HacError
+    enc = encoder(2)
+    ids = np.full((2, 16), 5, np.int32)
+    mask = np.ones((2, 16), np.int32)
+    mask[1, 3] = 0                       # hole: not a prefix mask
+    with pytest.raises(HacError):
+        enc(ids, mask)
+    mask[:] = 1
+    mask[0] = 0                          # empty sequence
+    with pytest.raises(HacError):
+        enc(ids, mask)
+    with pytest.raises(HacError):
+        enc(np.zeros((1, 600), np.int32), np.ones((1, 600), np.int32))   # longer than RoBERTa's 512 positions
+
+
+def test_missing_weight_is_reported():
+    from haconvdr_amd._lib import HacError
+    from haconvdr_amd.encoder import ANCEEncoder
+    sd = dict(state_dict(2))
+    del sd["roberta.encoder.layer.1.output.dense.bias"]
+    with pytest.raises(HacError) as e:
+        ANCEEncoder(n_layers=2).load_state_dict(sd)
+    assert "output.dense.bias" in str(e.value)
