@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--nq", type=int, default=1000)
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-encode", action="store_true", help="skip the encode / end-to-end extras")
+    ap.add_argument("--query-len", type=int, default=512, help="padded query length (TopiOCQA: 512, QReCC: 256)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample")
     args = ap.parse_args()
 
@@ -185,6 +187,62 @@ def main():
                                   f"oracle/flat_ip_oracle.c (OpenMP, AVX2 fmaf chain), {tcpu:.1f} s",
                         "ids_and_scores_equal_to_gpu": same}
 
+    # ---- extras: ANCE query encode (bf16 MFMA GEMMs) and end-to-end encode + top-k ------------------
+    encode = end_to_end = None
+    if not args.no_encode:
+        from haconvdr_amd import synth
+        from haconvdr_amd.encoder import ANCEEncoder
+        enc = ANCEEncoder.from_state_dict(synth.ance_state_dict(0xA11CE, 12, rich=False), device=local_rank)
+        Lq = args.query_len
+        nq_loc = (args.nq + world - 1) // world                       # queries are encoded data-parallel
+        tok, _ = synth.token_batch(0x70C + rank, nq_loc, Lq, fixed_len=Lq)   # fully padded = the reference's behaviour
+        ids_t = torch.from_numpy(tok.astype(np.int64)).to(dev)
+        mask_t = torch.ones_like(ids_t)
+
+        def e2e_step():
+            emb = enc(ids_t, mask_t)
+            if world > 1:
+                allq = torch.empty((world * nq_loc, D_EMB), dtype=torch.float32, device=dev)
+                dist.all_gather_into_tensor(allq, emb)
+                emb = allq[:args.nq]
+            return searcher.search(emb.contiguous(), args.k)
+
+        for _ in range(2):
+            enc(ids_t, mask_t)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n_enc = 3
+        enc.set_profiling(True)
+        for _ in range(n_enc):
+            enc(ids_t, mask_t)
+        torch.cuda.synchronize()
+        dt_enc = (time.perf_counter() - t1) / n_enc
+        stack_ms = float(np.sum(enc.profile_drain())) / n_enc     # a forward may run as several sub-batches
+        enc.set_profiling(False)
+        fl = nq_loc * 12.0 * (14155776.0 * Lq + 4.0 * Lq * Lq * 768.0) + nq_loc * 2.0 * 768 * 768
+        encode = {"queries_per_sec_per_gpu": round(nq_loc / dt_enc, 1), "seq_len": Lq, "batch": nq_loc, "ms": round(dt_enc * 1e3, 3),
+                  "layer_stack_ms": round(stack_ms, 3), "achieved_TFLOPs": round(fl / (stack_ms * 1e-3) / 1e12, 1),
+                  "mfma_bf16_frac_of_2.5PF": round(fl / (stack_ms * 1e-3) / 2.5e15, 4), "dtype": "bf16 MFMA operands, fp32 accumulate/LN/softmax",
+                  "weights": "synthetic N(0,0.02) RoBERTa-base"}
+        e2e_step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        n_e2e = 3
+        for _ in range(n_e2e):
+            e2e_step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt_e2e = (time.perf_counter() - t1) / n_e2e
+        if world > 1:
+            t = torch.tensor([dt_e2e], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_e2e = float(t.item())
+        end_to_end = {"queries_per_sec": round(args.nq / dt_e2e, 1), "ms_per_step": round(dt_e2e * 1e3, 3),
+                      "what": f"ANCE encode of {args.nq} queries (L={Lq}, data-parallel over {world} GPU) + exact top-{args.k} over {args.rows} passages"}
+
     if rank == 0:
         out = {
             "metric": "queries/sec (top-100 exact IP search) over N-passage 768-d corpus",
@@ -198,6 +256,8 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "hbm_regime": hbm_regime,
+            "encode": encode,
+            "end_to_end": end_to_end,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
