@@ -575,6 +575,100 @@ __global__ __launch_bounds__(W * 64) void scanq_kernel(ScanArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ threshold seeding
+// A lower bound of every query's final k-th score lets the scan kernels reject almost every row
+// with one compare.  It is the exact k-th largest score over an evenly strided sample of groups:
+//   sample_scores_kernel  scores [nq][S] of the sample (same MFMA chain as the scans, no top-k)
+//   kth_select_kernel     per query, exact k-th largest by 4-pass 8-bit radix select
+// The bound only filters; results never depend on it.
+__global__ __launch_bounds__(SCAN_WAVES * 64) void sample_scores_kernel(ScanArgs a, float *__restrict__ scores, u32 S) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K4 = a.K4;
+    const int q0 = blockIdx.y * 16;
+    const int QTr = min(16, a.nq - q0);
+    f4 *ldsQ = reinterpret_cast<f4 *>(smem);  // [K4][QTr]
+    for (int idx = tid; idx < K4 * QTr; idx += SCAN_WAVES * 64) {
+        const int k4 = idx / QTr, j = idx - k4 * QTr;
+        ldsQ[idx] = as_global(a.q)[(size_t)(q0 + j) * K4 + k4];
+    }
+    __syncthreads();
+    const u32 item = blockIdx.x * SCAN_WAVES + w;
+    if (item >= a.n_items) return;
+    const u32 g = a.g_first + item * a.g_step;
+    const int j = lane & 15;
+    const f4 *qb = ldsQ + min(j, QTr - 1);
+    gf4ptr gp = group_ptr(a, g) + lane;
+    f4 ring[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) ring[i] = gp[i * 64];
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f4 bcur = qb[0], bnxt;
+    const int NB = K4 / PF;
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (int tb = 0; tb < NB; ++tb) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int t = tb * PF + i;
+            bnxt = qb[min(t + 1, K4 - 1) * QTr];
+            const f4 av = ring[i];
+            HAC_MFMA4(av, bcur)
+            ring[i] = gp[min(t + PF, K4 - 1) * 64];
+            bcur = bnxt;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (j < QTr) {
+        const long rem = a.n_rows - (long)g * GROUP_ROWS;
+        float *out = scores + (size_t)(q0 + j) * S + (size_t)item * GROUP_ROWS;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int row = 16 * (rr >> 2) + 4 * (lane >> 4) + (rr & 3);
+            out[row] = row < rem ? acc[rr] : -INFINITY;
+        }
+    }
+}
+
+// thr[q] = k-th largest of scores[q][0..S) (NaN counts as -inf); -inf when fewer than k finite-or-inf entries
+__global__ __launch_bounds__(256) void kth_select_kernel(const float *__restrict__ scores, u32 S, int k, float *__restrict__ thr) {
+    __shared__ u32 hist[256];
+    __shared__ u32 sel_prefix, sel_k;
+    const int tid = threadIdx.x;
+    const float *src = scores + (size_t)blockIdx.x * S;
+    u32 prefix = 0, mask = 0, kk = (u32)k;  // keys matching (key & mask) == prefix are still candidates
+    for (int pass = 3; pass >= 0; --pass) {
+        hist[tid] = 0;
+        __syncthreads();
+        const int shift = pass * 8;
+        for (u32 i = tid; i < S; i += 256) {
+            const float v = src[i];
+            const u32 key = (v != v) ? 0u : f2ord(v + 0.0f);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            u32 cum = 0;
+            int b = 255;
+            for (; b > 0; --b) {
+                if (cum + hist[b] >= kk) break;
+                cum += hist[b];
+            }
+            sel_prefix = prefix | ((u32)b << shift);
+            sel_k = kk - cum;
+        }
+        __syncthreads();
+        prefix = sel_prefix;
+        kk = sel_k;
+        mask |= 255u << shift;
+        __syncthreads();
+    }
+    // prefix is the key of the k-th largest element if at least k keys exist; with fewer, the walk
+    // bottoms out in bin 0 chains (key 0 = NaN/-nothing): report -inf
+    if (tid == 0) thr[blockIdx.x] = (S >= (u32)k && prefix != 0u) ? ord2f(prefix) : -INFINITY;
+}
+
 // ------------------------------------------------------------------ merge kernel
 // One workgroup per query: streams L lists of k keys, keeps the k largest.
 // Element (l, q, i) lives at lists[l*stride_l + q*stride_q + i].
@@ -707,6 +801,7 @@ struct DeviceIndex {
                                 (const void *)scanq_kernel<4, 4>, (const void *)scanq_kernel<1, 8>, (const void *)scanq_kernel<2, 8>,
                                 (const void *)scanq_kernel<3, 8>, (const void *)scanq_kernel<4, 8>};
             for (const void *f : fq) HAC_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+            HAC_HIP(hipFuncSetAttribute((const void *)sample_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * 1024)));
             attr_done[device] = true;
         }
         return HAC_OK;
@@ -886,13 +981,13 @@ struct DeviceIndex {
 
     static size_t scanq_lds(int NQ, int C) { return (size_t)NQ * (2 * 16 * 16 + (size_t)C * 8 + 8) + 16; }
 
-    int make_plan(int64_t nq, int k, u32 n_items, Plan &pl) const {
+    int make_plan(int64_t nq, int k, u32 n_items, Plan &pl, bool want16 = false) const {
         pl.kind = 0;
         pl.NT = 0;
         pl.W = SCAN_WAVES;
         // many queries: GEMM-shaped kernel, NQ = 32*NT queries per workgroup
         const char *force = getenv("HAC_FORCE_SCAN16");
-        if (nq > 16 && K4 % 16 == 0 && !(force && force[0] == '1')) {
+        if (nq > 16 && K4 % 16 == 0 && !want16 && !(force && force[0] == '1')) {
             const int C2 = (int)std::max<u32>(32u, next_pow2((u32)k + 1u));
             int best_nt = 0;
             int64_t best_pad = 0;
@@ -1033,13 +1128,25 @@ struct DeviceIndex {
         // lower bound of every query's final k-th score; it only filters, never decides.
         const u32 n_sample = std::max<u32>(256u, G / 64u);
         if (G >= 4u * n_sample && (int64_t)n_sample * GROUP_ROWS >= 4 * (int64_t)k) {
-            HAC_TRY(ws_seedkeys.reserve((size_t)nq * k * 8));
+            const u32 S = n_sample * GROUP_ROWS;
+            HAC_TRY(ws_seedkeys.reserve((size_t)nq * S * 4));   // sample scores [nq][S]
             HAC_TRY(ws_thr.reserve((size_t)nq * 4));
-            const u32 step = G / n_sample;
-            const int Ps = (int)std::max<long>(1, std::min<long>(pl.P, (n_sample + pl.W - 1) / pl.W));
-            HAC_TRY(run_scan(pl, q_dev, nq, k, 0, step, n_sample, nullptr, pos_base, Ps, st, false));
-            HAC_TRY(run_merge(pl, (const u64 *)ws_partial.p, Ps, (size_t)k, (size_t)Ps * k, nq, k, (u64 *)ws_seedkeys.p,
-                              (float *)ws_thr.p, st));
+            ScanArgs a{};
+            a.segs = d_segs;
+            a.nseg = nseg_live;
+            a.q = reinterpret_cast<const float4 *>(q_dev);
+            a.nq = (int)nq;
+            a.K4 = K4;
+            a.n_rows = (long)ntotal;
+            a.g_first = 0;
+            a.g_step = G / n_sample;
+            a.n_items = n_sample;
+            const int qt16 = (int)((nq + 15) / 16);
+            sample_scores_kernel<<<dim3((n_sample + SCAN_WAVES - 1) / SCAN_WAVES, (unsigned)qt16), dim3(SCAN_WAVES * 64),
+                                   (size_t)K4 * 16 * 16, st>>>(a, (float *)ws_seedkeys.p, S);
+            HAC_HIP(hipGetLastError());
+            kth_select_kernel<<<dim3((unsigned)nq), dim3(256), 0, st>>>((const float *)ws_seedkeys.p, S, k, (float *)ws_thr.p);
+            HAC_HIP(hipGetLastError());
             thr_init = (const float *)ws_thr.p;
         }
         if (pl.kind == 1)

@@ -22,6 +22,25 @@ def short(name):
     return name.split("(")[0]
 
 
+def split_bimodal(groups, meta):
+    """The seed scan and the main scan share kernel and grid; their durations differ by >10x.
+    Split such groups at the geometric mean so that each population gets its own row."""
+    out, om = {}, {}
+    for key, us in groups.items():
+        lo, hi = min(us), max(us)
+        if lo > 0 and hi > 4 * lo:
+            cut = (lo * hi) ** 0.5
+            a = [u for u in us if u < cut]
+            b = [u for u in us if u >= cut]
+            out[key + ("short",)] = a
+            out[key + ("long",)] = b
+            om[key + ("short",)] = om[key + ("long",)] = meta[key]
+        else:
+            out[key + ("",)] = us
+            om[key + ("",)] = meta[key]
+    return out, om
+
+
 def main():
     d, prefix = sys.argv[1], sys.argv[2]
     extra = {}
@@ -42,21 +61,32 @@ def main():
             meta[key] = dict(lds=int(r["LDS_Block_Size"]), vgpr=int(r["VGPR_Count"]), agpr=int(r["Accum_VGPR_Count"]),
                              sgpr=int(r["SGPR_Count"]), scratch=int(r["Scratch_Size"]))
             disp[r["Dispatch_Id"]] = key
+    groups, meta = split_bimodal(groups, meta)
     for key, us in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
         us_sorted = sorted(us)
-        out["kernels"].append({"kernel": key[0], "grid_threads": [int(key[1]), int(key[2])], "block": int(key[3]),
+        out["kernels"].append({"kernel": key[0] + (f" [{key[4]} runs]" if key[4] else ""), "grid_threads": [int(key[1]), int(key[2])], "block": int(key[3]),
                                "calls": len(us), "avg_us": round(sum(us) / len(us), 2), "min_us": round(us_sorted[0], 2),
                                "median_us": round(us_sorted[len(us) // 2], 2), "max_us": round(us_sorted[-1], 2),
                                "total_ms": round(sum(us) / 1e3, 3), **meta[key]})
     counters = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
     if counters:
         agg = defaultdict(lambda: defaultdict(list))
+        rows = []
+        durs = defaultdict(list)
         for c in counters:
             for r in csv.DictReader(open(c)):
                 if "hac::" not in r["Kernel_Name"]:
                     continue
                 key = (short(r["Kernel_Name"]), r["Grid_Size"], r["Workgroup_Size"])
-                agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+                rows.append((key, r["Counter_Name"], float(r["Counter_Value"]), dur))
+                durs[key].append(dur)
+        for key, name, val, dur in rows:
+            lo, hi = min(durs[key]), max(durs[key])
+            tag = ""
+            if lo > 0 and hi > 4 * lo:
+                tag = " [short runs]" if dur < (lo * hi) ** 0.5 else " [long runs]"
+            agg[(key[0] + tag, key[1], key[2])][name].append(val)
         out["counters"] = []
         for key, cs in agg.items():
             row = {"kernel": key[0], "grid_threads_total": int(key[1]), "block": int(key[2])}
