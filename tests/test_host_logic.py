@@ -105,3 +105,13 @@ def test_sharded_search_gloo_world2(oracle):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
         assert "OK" in o
+
+
+def test_trec_writer_matches_reference(tmp_path):
+    """output_test_res mirror vs the file the reference's own output_test_res wrote (golden)."""
+    import argparse
+    from haconvdr_amd.trec import output_test_res
+    g = np.load(os.path.join(ROOT, "tests", "golden", "trec_case.npz"))
+    args = argparse.Namespace(top_k=int(g["topN"]), qrel_output_path=str(tmp_path), output_trec_file="run.trec")
+    path = output_test_res([str(q) for q in g["qids"]], g["score_mat"], g["pid_mat"], [int(x) for x in g["offset2pid"]], args)
+    assert open(path).read() == str(g["trec_text"])
