@@ -38,7 +38,7 @@ constexpr int NH = 12;        // heads
 constexpr int DH = 64;        // head dim
 constexpr int FF = 3072;      // FFN inner size
 constexpr int SEQ_ALIGN = 32; // rows per sequence are padded to this
-constexpr int MT = 128, NTILE = 128, BK = 64;
+constexpr int MT = 256, BK = 64;   // packed rows are padded to MT (largest GEMM tile)
 
 // ------------------------------------------------------------------ small helpers
 __device__ __forceinline__ float wave_sum(float v) {
@@ -224,104 +224,101 @@ struct GemmArgs {
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
-    // LDS: two stages of {A tile 128x64, W tile 128x64} bf16; 16-byte chunk c of row r lives at
-    // r*128 + ((c ^ (r & 7)) << 4)   (XOR swizzle: the 8 rows of a ds_read_b128 lane group hit 8 distinct slots)
+// TMT = 32-row MFMA tiles per wave along M.  TMT=2: 128x128 tile, 4 waves (2x2), 64 KiB LDS, 2 WG/CU
+// (small M).  TMT=4: 256x256 tile, 8 waves (2x4), wave tile 128x64, 128 KiB LDS, 1 WG/CU: twice the
+// flops per byte staged — at 128^2 the kernel is bound by L2->LDS traffic (64 flop/B needs 39 TB/s).
+template <int EPI, int TMT>
+__global__ __launch_bounds__(TMT * 128, TMT == 2 ? 2 : 2) void gemm_bf16_nt_kernel(GemmArgs g) {
+    // LDS: two stages of {A tile BMx64, W tile BNx64} bf16; 16-byte chunk c of row r lives at
+    // r*128 + ((c ^ (r & 7)) << 4): the 8 rows of a ds_read_b128 lane group hit 8 distinct slots.
+    // Tiles arrive by LDS-DMA (global_load_lds_dwordx4, 1 KiB = 8 rows per wave-instruction, no
+    // VGPRs, no ds_write); the DMA destination is lane-linear, so the swizzle is applied to the
+    // per-lane SOURCE address (chunk (lane&7) ^ (lane>>3) of row lane>>3).
+    constexpr int BM = 64 * TMT, BN = BM;
+    constexpr int STAGE = (BM + BN) * 128;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.y * MT, n0 = blockIdx.x * NTILE;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give every XCD a
+    // contiguous run of tiles; consecutive tiles of a run share the A rows (L2 reuse of activations).
+    const int nx = gridDim.x, nwg = gridDim.x * gridDim.y;
+    const int id = blockIdx.y * nx + blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7;
+    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
+    const int m0 = (wgid / nx) * BM, n0 = (wgid % nx) * BN;
     if (m0 >= *g.total_rows) return;
     const int K = g.K, KT = K / BK;
-    const int wm = w >> 1, wn = w & 1;
+    constexpr int WN = BN / 64;           // waves along N (2 or 4); 2 along M
+    const int wm = w / WN, wn = w % WN;
     const int r = lane & 31, hh = lane >> 5;
 
-    typedef const __attribute__((address_space(1))) f4v *gptr;
-    // staging: 1024 16-byte chunks per operand tile, 4 per thread
-    gptr ga[4], gw[4];
-    int lds_off[4];
+    typedef const __attribute__((address_space(1))) void *gvp;
+    typedef __attribute__((address_space(3))) void *lvp;
+    const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+    const bf16 *gA = g.A + (size_t)(m0 + w * 32 + srow) * K + schunk * 8;
+    const bf16 *gW = g.W + (size_t)(n0 + w * 32 + srow) * K + schunk * 8;
+    auto stage = [&](int buf, int kt) {
+        unsigned char *sb = smem + buf * STAGE + w * 4096;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ch = tid + i * 256;
-        const int row = ch >> 3, c = ch & 7;
-        ga[i] = (gptr)(g.A + (size_t)(m0 + row) * K + c * 8);
-        gw[i] = (gptr)(g.W + (size_t)(n0 + row) * K + c * 8);
-        lds_off[i] = row * 128 + ((c ^ (row & 7)) << 4);
-    }
-    f4v ra[4], rw[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        ra[i] = ga[i][0];
-        rw[i] = gw[i][0];
-    }
-    unsigned char *As = smem, *Ws = smem + 2 * MT * 128;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        *reinterpret_cast<f4v *>(As + lds_off[i]) = ra[i];
-        *reinterpret_cast<f4v *>(Ws + lds_off[i]) = rw[i];
-    }
-    __syncthreads();
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((gvp)(gA + (size_t)i * 8 * K + kt * BK), (lvp)(sb + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gvp)(gW + (size_t)i * 8 * K + kt * BK), (lvp)(sb + BM * 128 + i * 1024), 16, 0, 0);
+        }
+    };
+    stage(0, 0);
 
-    f32x16 acc[2][2];
+    f32x16 acc[TMT][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TMT; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-    // fragment row offsets (bytes) inside a stage
-    int arow[2], wrow[2];
+    // fragment byte offsets inside a stage, per k-step: row*128 + ((2*ks+hh) ^ (row&7))*16
+    int aoff[TMT], woff[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        arow[t] = wm * 64 + t * 32 + r;
-        wrow[t] = wn * 64 + t * 32 + r;
-    }
+    for (int t = 0; t < TMT; ++t) aoff[t] = (wm * (32 * TMT) + t * 32 + r) * 128;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) woff[t] = BM * 128 + (wn * 64 + t * 32 + r) * 128;
+    const int sw = r & 7;  // (row & 7) is the same for every fragment row of a lane
+    __syncthreads();
 
     for (int kt = 0; kt < KT; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < KT) {
+        if (kt + 1 < KT) stage(cur ^ 1, kt + 1);
+        const unsigned char *sc = smem + cur * STAGE;
+        bf16x8 af[2][TMT], wf[2][2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ra[i] = ga[i][(size_t)(kt + 1) * (BK / 8)];
-                rw[i] = gw[i][(size_t)(kt + 1) * (BK / 8)];
-            }
-        }
-        const unsigned char *Ac = As + cur * (MT * 128), *Wc = Ws + cur * (NTILE * 128);
+        for (int t = 0; t < TMT; ++t) af[0][t] = *reinterpret_cast<const bf16x8 *>(sc + aoff[t] + ((hh ^ sw) << 4));
+#pragma unroll
+        for (int t = 0; t < 2; ++t) wf[0][t] = *reinterpret_cast<const bf16x8 *>(sc + woff[t] + ((hh ^ sw) << 4));
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const int c = ks * 2 + hh;
-            bf16x8 af[2], wf[2];
+            if (ks < 3) {
+                const int c = ((ks + 1) * 2 + hh) ^ sw;
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                af[t] = *reinterpret_cast<const bf16x8 *>(Ac + arow[t] * 128 + ((c ^ (arow[t] & 7)) << 4));
-                wf[t] = *reinterpret_cast<const bf16x8 *>(Wc + wrow[t] * 128 + ((c ^ (wrow[t] & 7)) << 4));
+                for (int t = 0; t < TMT; ++t) af[(ks + 1) & 1][t] = *reinterpret_cast<const bf16x8 *>(sc + aoff[t] + (c << 4));
+#pragma unroll
+                for (int t = 0; t < 2; ++t) wf[(ks + 1) & 1][t] = *reinterpret_cast<const bf16x8 *>(sc + woff[t] + (c << 4));
             }
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < TMT; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], wf[b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][a], wf[ks & 1][b], acc[a][b], 0, 0, 0);
         }
-        if (kt + 1 < KT) {
-            unsigned char *An = As + (cur ^ 1) * (MT * 128), *Wn = Ws + (cur ^ 1) * (NTILE * 128);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                *reinterpret_cast<f4v *>(An + lds_off[i]) = ra[i];
-                *reinterpret_cast<f4v *>(Wn + lds_off[i]) = rw[i];
-            }
-        }
-        __syncthreads();
+        __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) here: next stage landed, this one is free
     }
 
-    // epilogue.  acc[a][b][e]: n = n0 + wn*64 + b*32 + r ; m = m0 + wm*64 + a*32 + (e&3) + 8*(e>>2) + 4*hh
+    // epilogue.  acc[a][b][e]: n = n0 + wn*64 + b*32 + r ; m = m0 + wm*32*TMT + a*32 + (e&3) + 8*(e>>2) + 4*hh
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int n = n0 + wn * 64 + b * 32 + r;
         const float bias = g.bias[n];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int mb = m0 + wm * 64 + a * 32 + 4 * hh;
+        for (int a = 0; a < TMT; ++a) {
+            const int mb = m0 + wm * (32 * TMT) + a * 32 + 4 * hh;
             if constexpr (EPI == EPI_QKV) {
                 if (n < 2 * H) {
                     bf16 *dst = n < H ? g.q : g.k;
@@ -369,101 +366,155 @@ struct AttnArgs {
     SeqInfo s;
 };
 
-__global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
+// Workgroup = 4 waves = 256 query rows of one (sequence, head); each wave owns TWO 32-row query blocks,
+// so every K and V^T fragment feeds two MFMAs.  The head's K (len32 x 64 bf16, <= 64 KiB) is staged
+// once per workgroup into LDS by LDS-DMA with the GEMM's XOR swizzle (conflict-free ds_read_b128);
+// V^T fragments come straight from L2 (8-byte loads in the permuted key order of the P operand).
+// Measured before this structure: every wave fetched K twice and V once from L2 per key block and the
+// kernel ran at the L2's ~6 TB/s.
+__global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // K image: row*128 + ((c ^ (row&7)) << 4)
     const int lane = threadIdx.x & 63;
-    const int w = threadIdx.x >> 6;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.z, head = blockIdx.y;
-    const int qb = blockIdx.x * 4 + w;
     const int len32 = a.s.len32[b];
-    if (qb * 32 >= len32) return;  // no barriers below: whole waves may leave
+    const int qbase = blockIdx.x * 256;
+    if (qbase >= len32) return;  // whole workgroup leaves before any barrier
     const int len = a.s.lens[b];
     const size_t base = (size_t)a.s.off[b];
     const int r = lane & 31, hh = lane >> 5;
     const int nkb = len32 >> 5;
 
+    {   // stage K[base .. base+len32)[head*64 .. +64) -> LDS, 8 rows (1 KiB) per wave-instruction
+        typedef const __attribute__((address_space(1))) void *gvp;
+        typedef __attribute__((address_space(3))) void *lvp;
+        const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+        const bf16 *src = a.k + (base + srow) * H + head * DH + schunk * 8;
+        for (int r8 = w; r8 * 8 < len32; r8 += 4)
+            __builtin_amdgcn_global_load_lds((gvp)(src + (size_t)r8 * 8 * H), (lvp)(smem + r8 * 1024), 16, 0, 0);
+    }
+    __syncthreads();  // hipcc drains the LDS-DMA here
+    const int q0 = qbase + w * 64;
+    if (q0 >= len32) return;  // no barriers below
+
     // Q^T fragments (B operand of S^T = K.Q^T): lane (q = r, half hh) holds q[16*ks + 8*hh .. +8)
-    bf16x8 qf[4];
-    const bf16 *qrow = a.q + (base + qb * 32 + r) * H + head * DH + 8 * hh;
+    bf16x8 qf[2][4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8 *>(qrow + ks * 16);
-    const bf16 *kbase = a.k + (base + r) * H + head * DH + 8 * hh;
+    for (int u = 0; u < 2; ++u) {
+        const bf16 *qrow = a.q + (base + q0 + u * 32 + r) * H + head * DH + 8 * hh;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[u][ks] = *reinterpret_cast<const bf16x8 *>(qrow + ks * 16);
+    }
+    const unsigned char *krow = smem + r * 128;
+    const int sw = r & 7;
 
     // pass 1: row maxima.  S^T tile: lane column = query r, register e <-> key (e&3) + 8*(e>>2) + 4*hh
-    float mx = -INFINITY;
+    float mx[2] = {-INFINITY, -INFINITY};
     for (int kb = 0; kb < nkb; ++kb) {
-        f32x16 s;
+        f32x16 s[2];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) s[e] = 0.f;
-        const bf16 *kp = kbase + (size_t)kb * 32 * H;
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[u][e] = 0.f;
+        const unsigned char *kp = krow + kb * 4096;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(kp + ks * 16);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+            const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(kp + (((2 * ks + hh) ^ sw) << 4));
+#pragma unroll
+            for (int u = 0; u < 2; ++u) s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[u][ks], s[u], 0, 0, 0);
         }
         const int k0 = kb * 32 + 4 * hh;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int key = k0 + (e & 3) + 8 * (e >> 2);
-            if (key < len) mx = fmaxf(mx, s[e]);
+            if (key < len) {
+                mx[0] = fmaxf(mx[0], s[0][e]);
+                mx[1] = fmaxf(mx[1], s[1][e]);
+            }
         }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float L2E = 1.44269504088896341f;
+    float mxs[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        mx[u] = fmaxf(mx[u], __shfl_xor(mx[u], 32));
+        mxs[u] = mx[u] * L2E;
+    }
 
     // pass 2: P = exp(S - max), l = sum P, O = P.V
-    float lsum = 0.f;
-    f32x16 o[2];
+    float lsum[2] = {0.f, 0.f};
+    f32x16 o[2][2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) o[t][e] = 0.f;
-    const float L2E = 1.44269504088896341f;
-    const float mxs = mx * L2E;
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[u][t][e] = 0.f;
     const bf16 *vbase = a.vt + (size_t)(head * DH + r) * a.ldvt + base + 4 * hh;
     for (int kb = 0; kb < nkb; ++kb) {
-        f32x16 s;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) s[e] = 0.f;
-        const bf16 *kp = kbase + (size_t)kb * 32 * H;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(kp + ks * 16);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
-        }
-        const int k0 = kb * 32 + 4 * hh;
-        bf16x8 pf[2];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int key = k0 + (e & 3) + 8 * (e >> 2);
-            const float p = key < len ? exp2f(s[e] * L2E - mxs) : 0.f;
-            lsum += p;
-            pf[e >> 3][e & 7] = (bf16)p;
-        }
-        // P (registers 8s..8s+7 of the S^T accumulator) is the A operand of k-step s; slot j of half hh is
-        // key 16s + 8(j>>2) + 4hh + (j&3): V^T fragments are fetched in exactly that key order.
+        // V^T fragments first: their L2 latency hides under the S^T MFMAs and the exponentials
+        bf16x4 v0[2][2], v1[2][2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const bf16 *vp = vbase + (size_t)(t * 32) * a.ldvt + kb * 32;
 #pragma unroll
             for (int sidx = 0; sidx < 2; ++sidx) {
-                const bf16x4 v0 = *reinterpret_cast<const bf16x4 *>(vp + 16 * sidx);
-                const bf16x4 v1 = *reinterpret_cast<const bf16x4 *>(vp + 16 * sidx + 8);
-                bf16x8 vf;
-                vf[0] = v0.x; vf[1] = v0.y; vf[2] = v0.z; vf[3] = v0.w;
-                vf[4] = v1.x; vf[5] = v1.y; vf[6] = v1.z; vf[7] = v1.w;
-                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[sidx], vf, o[t], 0, 0, 0);
+                v0[t][sidx] = *reinterpret_cast<const bf16x4 *>(vp + 16 * sidx);
+                v1[t][sidx] = *reinterpret_cast<const bf16x4 *>(vp + 16 * sidx + 8);
             }
         }
+        f32x16 s[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[u][e] = 0.f;
+        const unsigned char *kp = krow + kb * 4096;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(kp + (((2 * ks + hh) ^ sw) << 4));
+#pragma unroll
+            for (int u = 0; u < 2; ++u) s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[u][ks], s[u], 0, 0, 0);
+        }
+        const int k0 = kb * 32 + 4 * hh;
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int key = k0 + (e & 3) + 8 * (e >> 2);
+            const bool valid = key < len;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float p = valid ? exp2f(s[u][e] * L2E - mxs[u]) : 0.f;
+                lsum[u] += p;
+                pf[u][e >> 3][e & 7] = (bf16)p;
+            }
+        }
+        // P (registers 8s..8s+7 of the S^T accumulator) is the A operand of k-step s; slot j of half hh is
+        // key 16s + 8(j>>2) + 4hh + (j&3): V^T fragments were fetched in exactly that key order.
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int sidx = 0; sidx < 2; ++sidx) {
+                bf16x8 vf;
+                vf[0] = v0[t][sidx].x; vf[1] = v0[t][sidx].y; vf[2] = v0[t][sidx].z; vf[3] = v0[t][sidx].w;
+                vf[4] = v1[t][sidx].x; vf[5] = v1[t][sidx].y; vf[6] = v1[t][sidx].z; vf[7] = v1[t][sidx].w;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) o[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[u][sidx], vf, o[u][t], 0, 0, 0);
+            }
     }
-    lsum += __shfl_xor(lsum, 32);
-    const float inv = 1.0f / lsum;  // lane r holds 1/l of query r (both halves)
-    // O tile t: lane column = d = 32t + r, register e <-> query row (e&3) + 8*(e>>2) + 4*hh
-    bf16 *crow = a.ctx + (base + qb * 32) * H + head * DH + r;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int qr = (e & 3) + 8 * (e >> 2) + 4 * hh;
-        const float sc = __shfl(inv, qr);
+    for (int u = 0; u < 2; ++u) {
+        if (q0 + u * 32 >= len32) break;  // second block past the sequence: computed on foreign rows, never stored
+        const float l = lsum[u] + __shfl_xor(lsum[u], 32);
+        const float inv = 1.0f / l;  // lane r holds 1/l of query r (both halves)
+        // O tile t: lane column = d = 32t + r, register e <-> query row (e&3) + 8*(e>>2) + 4*hh
+        bf16 *crow = a.ctx + (base + q0 + u * 32) * H + head * DH + r;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) crow[(size_t)qr * H + 32 * t] = (bf16)(o[t][e] * sc);
+        for (int e = 0; e < 16; ++e) {
+            const int qr = (e & 3) + 8 * (e >> 2) + 4 * hh;
+            const float sc = __shfl(inv, qr);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) crow[(size_t)qr * H + 32 * t] = (bf16)(o[u][t][e] * sc);
+        }
     }
 }
 
@@ -610,8 +661,17 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
     embed_ln_kernel<IT><<<dim3(L32 / 4, B), dim3(256), 0, st>>>(ids, L, s, e->word, e->posw, e->typew, e->embg, e->embb, c.ln_eps, x, xb);
     HAC_HIP(hipGetLastError());
     const int *total = s.off + B;
-    const unsigned mt = (unsigned)(Mp / MT);
-    const size_t lds = 4 * MT * 128;
+    // tile choice: 256^2 tiles once they fill the chip, 128^2 tiles for small batches
+    const bool big = (Mp / 256) * (H / 256) >= 128;
+    const int bt = big ? 256 : 128;
+    const unsigned mt = (unsigned)(Mp / bt);
+    const size_t lds = (size_t)4 * bt * 128;
+    const dim3 blk(big ? 512 : 256);
+#define HAC_GEMM(EPI, NN)                                                                          \
+    do {                                                                                           \
+        if (big) gemm_bf16_nt_kernel<EPI, 4><<<dim3((NN) / 256, mt), blk, lds, st>>>(g);           \
+        else gemm_bf16_nt_kernel<EPI, 2><<<dim3((NN) / 128, mt), blk, lds, st>>>(g);               \
+    } while (0)
     if (e->profiling) {
         if (e->ev_used == e->ev_pool.size()) {
             hipEvent_t a0, a1;
@@ -627,21 +687,22 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
         g.total_rows = total;
         // QKV
         g.A = xb; g.W = w.wqkv; g.bias = w.bqkv; g.N = 3 * H; g.K = H; g.q = q; g.k = k; g.vt = vt; g.ldvt = ldvt;
-        gemm_bf16_nt_kernel<EPI_QKV><<<dim3(3 * H / NTILE, mt), dim3(256), lds, st>>>(g);
+        HAC_GEMM(EPI_QKV, 3 * H);
         AttnArgs a{q, k, vt, ldvt, ctx, s};
-        attention_kernel<<<dim3((L32 / 32 + 3) / 4, NH, B), dim3(256), 0, st>>>(a);
+        attention_kernel<<<dim3((L32 + 255) / 256, NH, B), dim3(256), (size_t)L32 * 128, st>>>(a);
         // attention output projection + residual, LN
         g.A = ctx; g.W = w.wo; g.bias = w.bo; g.N = H; g.K = H; g.resid = x; g.y = y;
-        gemm_bf16_nt_kernel<EPI_RESID><<<dim3(H / NTILE, mt), dim3(256), lds, st>>>(g);
+        HAC_GEMM(EPI_RESID, H);
         ln_rows_kernel<<<dim3((unsigned)(Mp / 4)), dim3(256), 0, st>>>(y, total, w.ln1g, w.ln1b, c.ln_eps, x, xb);
         // FFN
         g.A = xb; g.W = w.w1; g.bias = w.b1; g.N = FF; g.K = H; g.h = h;
-        gemm_bf16_nt_kernel<EPI_GELU><<<dim3(FF / NTILE, mt), dim3(256), lds, st>>>(g);
+        HAC_GEMM(EPI_GELU, FF);
         g.A = h; g.W = w.w2; g.bias = w.b2; g.N = H; g.K = FF; g.resid = x; g.y = y;
-        gemm_bf16_nt_kernel<EPI_RESID><<<dim3(H / NTILE, mt), dim3(256), lds, st>>>(g);
+        HAC_GEMM(EPI_RESID, H);
         ln_rows_kernel<<<dim3((unsigned)(Mp / 4)), dim3(256), 0, st>>>(y, total, w.ln2g, w.ln2b, c.ln_eps, x, xb);
         HAC_HIP(hipGetLastError());
     }
+#undef HAC_GEMM
     if (e->profiling) {
         HAC_HIP(hipEventRecord(e->ev_pool[e->ev_used].second, st));
         ++e->ev_used;
@@ -686,9 +747,13 @@ int hac_encoder_create(const hac_encoder_config *cfg, int device, hac_encoder **
         delete e;
         return fail(HAC_ERR_HIP, "hipStreamCreate failed");
     }
-    (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void *)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_QKV, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_RESID, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_GELU, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_QKV, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_RESID, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_GELU, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     *out = e;
     return HAC_OK;
 }
