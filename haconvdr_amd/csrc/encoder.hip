@@ -222,59 +222,75 @@ struct GemmArgs {
     bf16 *h;              // EPI_GELU: [Mp][N] bf16
 };
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// exact-erf GELU (hidden_act = "gelu").  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32
+// rounding level and 4 orders below the bf16 grid the result is stored on): 1 rcp + 1 exp2 + 7 fma
+// instead of ocml erff's branchy ~30 instructions on 400 M elements per FFN.  Evaluated on PAIRS so
+// that hipcc emits v_pk_fma_f32 / v_pk_mul_f32 (half the VALU issue slots; no MFMA runs beside the epilogue).
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2v gelu_erf2(f2v x) {
+    const f2v ax = {fabsf(x.x), fabsf(x.y)};
+    const f2v z = ax * 0.70710678118654752f;
+    const f2v d = z * 0.3275911f + 1.0f;
+    const f2v t = {__frcp_rn(d.x), __frcp_rn(d.y)};
+    f2v p = t * 1.061405429f + (-1.453152027f);
+    p = p * t + 1.421413741f;
+    p = p * t + (-0.284496736f);
+    p = p * t + 0.254829592f;
+    const f2v zz = z * z * (-1.44269504088896341f);
+    const f2v ex = {exp2f(zz.x), exp2f(zz.y)};
+    const f2v e = 1.0f - p * t * ex;                       // erf(|x|/sqrt2)
+    const f2v se = {copysignf(e.x, x.x), copysignf(e.y, x.y)};
+    return (x * 0.5f) * (se + 1.0f);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return gelu_erf2((f2v){x, x}).x; }
 
-// TMT = 32-row MFMA tiles per wave along M.  TMT=2: 128x128 tile, 4 waves (2x2), 64 KiB LDS, 2 WG/CU
-// (small M).  TMT=4: 256x256 tile, 8 waves (2x4), wave tile 128x64, 128 KiB LDS, 1 WG/CU: twice the
-// flops per byte staged — at 128^2 the kernel is bound by L2->LDS traffic (64 flop/B needs 39 TB/s).
+// TMT = 32-row MFMA tiles per wave along M.  TMT=2: 128x128 tile, 4 waves (2x2), 2 WG/CU (small M).
+// TMT=4: 256x256 tile, 8 waves (2x4), wave tile 128x64, 1 WG/CU: twice the flops per byte staged — at
+// 128^2 the kernel is bound by L2->LDS traffic (64 flop/B needs 39 TB/s).
+// PERSISTENT: one workgroup per CU slot walks a list of output tiles; the first k-tile of the NEXT
+// output tile is staged during the last k-step of the current one, so neither the first-load latency
+// nor the epilogue's stores are exposed (K = 768 means only 12 k-steps per tile).
 template <int EPI, int TMT>
-__global__ __launch_bounds__(TMT * 128, TMT == 2 ? 2 : 2) void gemm_bf16_nt_kernel(GemmArgs g) {
-    // LDS: two stages of {A tile BMx64, W tile BNx64} bf16; 16-byte chunk c of row r lives at
-    // r*128 + ((c ^ (r & 7)) << 4): the 8 rows of a ds_read_b128 lane group hit 8 distinct slots.
-    // Tiles arrive by LDS-DMA (global_load_lds_dwordx4, 1 KiB = 8 rows per wave-instruction, no
-    // VGPRs, no ds_write); the DMA destination is lane-linear, so the swizzle is applied to the
-    // per-lane SOURCE address (chunk (lane&7) ^ (lane>>3) of row lane>>3).
+__global__ __launch_bounds__(TMT * 128, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
+    // LDS: two stages of {A tile BMx64, W tile BNx64} bf16 + one 4 KiB transpose patch per wave.
+    // 16-byte chunk c of row r lives at r*128 + ((c ^ (r & 7)) << 4): the 8 rows of a ds_read_b128 lane
+    // group hit 8 distinct slots.  Tiles arrive by LDS-DMA (global_load_lds_dwordx4, 1 KiB = 8 rows per
+    // wave-instruction, no VGPRs, no ds_write); the DMA destination is lane-linear, so the swizzle is
+    // applied to the per-lane SOURCE address (chunk (lane&7) ^ (lane>>3) of row lane>>3).
     constexpr int BM = 64 * TMT, BN = BM;
     constexpr int STAGE = (BM + BN) * 128;
+    constexpr int WN = BN / 64;           // waves along N (2 or 4); 2 along M
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give every XCD a
-    // contiguous run of tiles; consecutive tiles of a run share the A rows (L2 reuse of activations).
-    const int nx = gridDim.x, nwg = gridDim.x * gridDim.y;
-    const int id = blockIdx.y * nx + blockIdx.x;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7;
-    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
-    const int m0 = (wgid / nx) * BM, n0 = (wgid % nx) * BN;
-    if (m0 >= *g.total_rows) return;
     const int K = g.K, KT = K / BK;
-    constexpr int WN = BN / 64;           // waves along N (2 or 4); 2 along M
+    const int nx = g.N / BN;
+    const int n_tiles = ((*g.total_rows + BM - 1) / BM) * nx;
+    // XCD-aware tile lists: workgroups are dealt round-robin over the 8 XCDs; XCD x owns the contiguous
+    // run [x*n/8, (x+1)*n/8) of tiles (consecutive tiles share the A rows -> L2 reuse of activations)
+    // and its workgroups take them round-robin.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = (gridDim.x + 7 - xcd) >> 3;
+    const int run_lo = (int)((long)n_tiles * xcd / 8), run_hi = (int)((long)n_tiles * (xcd + 1) / 8);
+    int tile = run_lo + slot;
+    if (tile >= run_hi) return;
     const int wm = w / WN, wn = w % WN;
     const int r = lane & 31, hh = lane >> 5;
 
     typedef const __attribute__((address_space(1))) void *gvp;
     typedef __attribute__((address_space(3))) void *lvp;
     const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
-    const bf16 *gA = g.A + (size_t)(m0 + w * 32 + srow) * K + schunk * 8;
-    const bf16 *gW = g.W + (size_t)(n0 + w * 32 + srow) * K + schunk * 8;
-    auto stage = [&](int buf, int kt) {
+    const size_t lane_src = (size_t)(w * 32 + srow) * K + schunk * 8;
+    auto stage = [&](int buf, int t, int kt) {
+        const int m0s = (t / nx) * BM, n0s = (t % nx) * BN;
+        const bf16 *gA = g.A + (size_t)m0s * K + lane_src + kt * BK;
+        const bf16 *gW = g.W + (size_t)n0s * K + lane_src + kt * BK;
         unsigned char *sb = smem + buf * STAGE + w * 4096;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds((gvp)(gA + (size_t)i * 8 * K + kt * BK), (lvp)(sb + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gvp)(gW + (size_t)i * 8 * K + kt * BK), (lvp)(sb + BM * 128 + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gvp)(gA + (size_t)i * 8 * K), (lvp)(sb + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gvp)(gW + (size_t)i * 8 * K), (lvp)(sb + BM * 128 + i * 1024), 16, 0, 0);
         }
     };
-    stage(0, 0);
-
-    f32x16 acc[TMT][2];
-#pragma unroll
-    for (int a = 0; a < TMT; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-
     // fragment byte offsets inside a stage, per k-step: row*128 + ((2*ks+hh) ^ (row&7))*16
     int aoff[TMT], woff[2];
 #pragma unroll
@@ -282,55 +298,68 @@ __global__ __launch_bounds__(TMT * 128, TMT == 2 ? 2 : 2) void gemm_bf16_nt_kern
 #pragma unroll
     for (int t = 0; t < 2; ++t) woff[t] = BM * 128 + (wn * 64 + t * 32 + r) * 128;
     const int sw = r & 7;  // (row & 7) is the same for every fragment row of a lane
+    float *patch = reinterpret_cast<float *>(smem + 2 * STAGE) + w * 1024;  // [16 rows][64 cols] fp32, wave-private
+
+    int cur = 0;
+    stage(0, tile, 0);
     __syncthreads();
+    for (; tile < run_hi; tile += per_xcd) {
+        const int m0 = (tile / nx) * BM, n0 = (tile % nx) * BN;
+        const int next_tile = tile + per_xcd;
+        f32x16 acc[TMT][2];
+#pragma unroll
+        for (int a = 0; a < TMT; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-    for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < KT) stage(cur ^ 1, kt + 1);
-        const unsigned char *sc = smem + cur * STAGE;
-        bf16x8 af[2][TMT], wf[2][2];
+        for (int kt = 0; kt < KT; ++kt) {
+#ifndef HAC_DBG_NOSTAGE   // (timing experiment only: main loop without its DMA)
+            if (kt + 1 < KT) stage(cur ^ 1, tile, kt + 1);
+            else if (next_tile < run_hi) stage(cur ^ 1, next_tile, 0);
+#endif
+            const unsigned char *sc = smem + cur * STAGE;
+            bf16x8 af[2][TMT], wf[2][2];
 #pragma unroll
-        for (int t = 0; t < TMT; ++t) af[0][t] = *reinterpret_cast<const bf16x8 *>(sc + aoff[t] + ((hh ^ sw) << 4));
+            for (int t = 0; t < TMT; ++t) af[0][t] = *reinterpret_cast<const bf16x8 *>(sc + aoff[t] + ((hh ^ sw) << 4));
 #pragma unroll
-        for (int t = 0; t < 2; ++t) wf[0][t] = *reinterpret_cast<const bf16x8 *>(sc + woff[t] + ((hh ^ sw) << 4));
+            for (int t = 0; t < 2; ++t) wf[0][t] = *reinterpret_cast<const bf16x8 *>(sc + woff[t] + ((hh ^ sw) << 4));
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            if (ks < 3) {
-                const int c = ((ks + 1) * 2 + hh) ^ sw;
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks < 3) {
+                    const int c = ((ks + 1) * 2 + hh) ^ sw;
 #pragma unroll
-                for (int t = 0; t < TMT; ++t) af[(ks + 1) & 1][t] = *reinterpret_cast<const bf16x8 *>(sc + aoff[t] + (c << 4));
+                    for (int t = 0; t < TMT; ++t) af[(ks + 1) & 1][t] = *reinterpret_cast<const bf16x8 *>(sc + aoff[t] + (c << 4));
 #pragma unroll
-                for (int t = 0; t < 2; ++t) wf[(ks + 1) & 1][t] = *reinterpret_cast<const bf16x8 *>(sc + woff[t] + (c << 4));
+                    for (int t = 0; t < 2; ++t) wf[(ks + 1) & 1][t] = *reinterpret_cast<const bf16x8 *>(sc + woff[t] + (c << 4));
+                }
+#pragma unroll
+                for (int a = 0; a < TMT; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][a], wf[ks & 1][b], acc[a][b], 0, 0, 0);
             }
-#pragma unroll
-            for (int a = 0; a < TMT; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][a], wf[ks & 1][b], acc[a][b], 0, 0, 0);
+            __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) here: next stage landed, this one is free
+            cur ^= 1;
         }
-        __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) here: next stage landed, this one is free
-    }
 
-    // epilogue.  acc[a][b][e]: n = n0 + wn*64 + b*32 + r ; m = m0 + wm*32*TMT + a*32 + (e&3) + 8*(e>>2) + 4*hh
+        // ---- epilogue.  acc[a][b][e] is element (m, n) with n = n0 + wn*64 + b*32 + r and
+        // m = m0 + wm*32*TMT + a*32 + (e&3) + 8*(e>>2) + 4*hh: a lane owns ONE column and 16 scattered
+        // rows, so storing from registers means 2- or 4-byte accesses.  Each wave instead transposes one
+        // 16x64 sub-tile at a time through its private LDS patch and then touches global memory
+        // row-wise with 16-byte accesses.  (The next tile's first k-step is already in LDS.)
+        const int ncol0 = n0 + wn * 64;
+        const float bias0 = g.bias[ncol0 + r], bias1 = g.bias[ncol0 + 32 + r];
+        if (EPI == EPI_QKV && n0 >= 2 * H) {
+            // V is written TRANSPOSED ([768][T]) for the attention kernel: 4 consecutive tokens per lane already
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int n = n0 + wn * 64 + b * 32 + r;
-        const float bias = g.bias[n];
+            for (int b = 0; b < 2; ++b) {
+                bf16 *dst = g.vt + (size_t)(ncol0 + b * 32 + r - 2 * H) * g.ldvt;
+                const float bias = b ? bias1 : bias0;
 #pragma unroll
-        for (int a = 0; a < TMT; ++a) {
-            const int mb = m0 + wm * (32 * TMT) + a * 32 + 4 * hh;
-            if constexpr (EPI == EPI_QKV) {
-                if (n < 2 * H) {
-                    bf16 *dst = n < H ? g.q : g.k;
-                    const int nn = n < H ? n : n - H;
-                    const float sc = n < H ? 0.125f : 1.0f;  // 1/sqrt(64) folded into Q (exact: power of two)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int m = mb + (e & 3) + 8 * (e >> 2);
-                        dst[(size_t)m * H + nn] = (bf16)((acc[a][b][e] + bias) * sc);
-                    }
-                } else {
-                    bf16 *dst = g.vt + (size_t)(n - 2 * H) * g.ldvt;  // V^T: 4 consecutive tokens per store
+                for (int a = 0; a < TMT; ++a) {
+                    const int mb = m0 + wm * (32 * TMT) + a * 32 + 4 * hh;
 #pragma unroll
                     for (int e4 = 0; e4 < 4; ++e4) {
                         bf16x4 o;
@@ -341,18 +370,66 @@ __global__ __launch_bounds__(TMT * 128, TMT == 2 ? 2 : 2) void gemm_bf16_nt_kern
                         *reinterpret_cast<bf16x4 *>(dst + mb + 8 * e4) = o;
                     }
                 }
-            } else if constexpr (EPI == EPI_RESID) {
+            }
+            continue;
+        }
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const size_t m = mb + (e & 3) + 8 * (e >> 2);
-                    g.y[m * H + n] = acc[a][b][e] + bias + g.resid[m * H + n];
-                }
-            } else {
+        for (int a = 0; a < TMT; ++a) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const size_t m = mb + (e & 3) + 8 * (e >> 2);
-                    g.h[m * g.N + n] = (bf16)gelu_erf(acc[a][b][e] + bias);
+            for (int half = 0; half < 2; ++half) {   // rows 16*half .. 16*half+15 of the 32-row MFMA tile
+                // residual rows of this sub-tile are requested first: their L2 latency hides under the transpose
+                f4v rs[4];
+                if constexpr (EPI == EPI_RESID) {
+                    const size_t mr = (size_t)m0 + wm * (32 * TMT) + a * 32 + half * 16;
+#pragma unroll
+                    for (int it = 0; it < 4; ++it)
+                        rs[it] = *reinterpret_cast<const f4v *>(g.resid + (mr + it * 4 + (lane >> 4)) * H + ncol0 + (lane & 15) * 4);
                 }
+#pragma unroll
+                for (int e8 = 0; e8 < 8; ++e8) {
+                    const int e = half * 8 + e8;
+                    const int row = (e8 & 3) + 8 * (e8 >> 2) + 4 * hh;   // 0..15
+                    patch[row * 64 + r] = acc[a][0][e] + bias0;
+                    patch[row * 64 + 32 + r] = acc[a][1][e] + bias1;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's own LDS writes have landed
+                __builtin_amdgcn_wave_barrier();
+                const size_t mrow = (size_t)m0 + wm * (32 * TMT) + a * 32 + half * 16;
+                if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int row = it * 4 + (lane >> 4), c4 = (lane & 15) * 4;
+                        const f4v v = *reinterpret_cast<const f4v *>(patch + row * 64 + c4);
+                        const size_t off = (mrow + row) * H + ncol0 + c4;
+                        *reinterpret_cast<f4v *>(g.y + off) = v + rs[it];
+                    }
+                } else {
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        const int row = it * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+                        const f4v v0 = *reinterpret_cast<const f4v *>(patch + row * 64 + c8);
+                        const f4v v1 = *reinterpret_cast<const f4v *>(patch + row * 64 + c8 + 4);
+                        bf16x8 o;
+                        if constexpr (EPI == EPI_GELU) {
+                            const f2v g0 = gelu_erf2((f2v){v0.x, v0.y}), g1 = gelu_erf2((f2v){v0.z, v0.w});
+                            const f2v g2 = gelu_erf2((f2v){v1.x, v1.y}), g3 = gelu_erf2((f2v){v1.z, v1.w});
+                            o[0] = (bf16)g0.x; o[1] = (bf16)g0.y; o[2] = (bf16)g1.x; o[3] = (bf16)g1.y;
+                            o[4] = (bf16)g2.x; o[5] = (bf16)g2.y; o[6] = (bf16)g3.x; o[7] = (bf16)g3.y;
+                            *reinterpret_cast<bf16x8 *>(g.h + (mrow + row) * (size_t)g.N + ncol0 + c8) = o;
+                        } else {  // Q (scaled by 1/sqrt(64): exact, a power of two) or K
+                            const float sc = n0 < H ? 0.125f : 1.0f;
+                            o[0] = (bf16)(v0.x * sc); o[1] = (bf16)(v0.y * sc); o[2] = (bf16)(v0.z * sc); o[3] = (bf16)(v0.w * sc);
+                            o[4] = (bf16)(v1.x * sc); o[5] = (bf16)(v1.y * sc); o[6] = (bf16)(v1.z * sc); o[7] = (bf16)(v1.w * sc);
+                            bf16 *dst = n0 < H ? g.q : g.k;
+                            const int nn = (n0 < H ? ncol0 : ncol0 - H) + c8;
+                            *reinterpret_cast<bf16x8 *>(dst + (mrow + row) * H + nn) = o;
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_s_waitcnt(0xC07F);  // reads done before the next sub-tile overwrites the patch
+                __builtin_amdgcn_wave_barrier();
             }
         }
     }
@@ -604,6 +681,7 @@ struct hac_encoder {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
     long max_tokens = 131072;  // packed rows per sub-batch
+    int n_cu = 256;
 };
 
 namespace {
@@ -661,16 +739,16 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
     embed_ln_kernel<IT><<<dim3(L32 / 4, B), dim3(256), 0, st>>>(ids, L, s, e->word, e->posw, e->typew, e->embg, e->embb, c.ln_eps, x, xb);
     HAC_HIP(hipGetLastError());
     const int *total = s.off + B;
-    // tile choice: 256^2 tiles once they fill the chip, 128^2 tiles for small batches
+    // tile choice: 256^2 tiles once they fill the chip, 128^2 tiles for small batches; persistent grids
     const bool big = (Mp / 256) * (H / 256) >= 128;
     const int bt = big ? 256 : 128;
-    const unsigned mt = (unsigned)(Mp / bt);
-    const size_t lds = (size_t)4 * bt * 128;
+    const size_t lds = (size_t)4 * bt * 128 + (size_t)(big ? 8 : 4) * 4096;   // 2 stages + per-wave patches
     const dim3 blk(big ? 512 : 256);
-#define HAC_GEMM(EPI, NN)                                                                          \
-    do {                                                                                           \
-        if (big) gemm_bf16_nt_kernel<EPI, 4><<<dim3((NN) / 256, mt), blk, lds, st>>>(g);           \
-        else gemm_bf16_nt_kernel<EPI, 2><<<dim3((NN) / 128, mt), blk, lds, st>>>(g);               \
+    const unsigned n_wg = (unsigned)(e->n_cu * (big ? 1 : 2));
+#define HAC_GEMM(EPI, NN)                                                             \
+    do {                                                                              \
+        if (big) gemm_bf16_nt_kernel<EPI, 4><<<dim3(n_wg), blk, lds, st>>>(g);         \
+        else gemm_bf16_nt_kernel<EPI, 2><<<dim3(n_wg), blk, lds, st>>>(g);             \
     } while (0)
     if (e->profiling) {
         if (e->ev_used == e->ev_pool.size()) {
@@ -748,12 +826,16 @@ int hac_encoder_create(const hac_encoder_config *cfg, int device, hac_encoder **
         return fail(HAC_ERR_HIP, "hipStreamCreate failed");
     }
     (void)hipFuncSetAttribute((const void *)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_QKV, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_RESID, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_GELU, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_QKV, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_RESID, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_GELU, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_QKV, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
+    (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_RESID, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
+    (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_GELU, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
+    (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_QKV, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_RESID, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_GELU, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) e->n_cu = prop.multiProcessorCount;
+    }
     *out = e;
     return HAC_OK;
 }
