@@ -315,10 +315,8 @@ __global__ __launch_bounds__(TMT * 128, 2) void gemm_bf16_nt_kernel(GemmArgs g) 
                 for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
         for (int kt = 0; kt < KT; ++kt) {
-#ifndef HAC_DBG_NOSTAGE   // (timing experiment only: main loop without its DMA)
             if (kt + 1 < KT) stage(cur ^ 1, tile, kt + 1);
             else if (next_tile < run_hi) stage(cur ^ 1, next_tile, 0);
-#endif
             const unsigned char *sc = smem + cur * STAGE;
             bf16x8 af[2][TMT], wf[2][2];
 #pragma unroll
