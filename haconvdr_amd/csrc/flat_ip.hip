@@ -176,7 +176,8 @@ struct ScanArgs {
     u32 g_first, g_step, n_items;  // work items i -> group g_first + i*g_step
     const float *thr_init;  // [nq] lower bounds of the final k-th score, or null
     u32 *thr_glob;          // [nq] chip-wide threshold, orderable-uint encoding, 0 = none
-    u64 *partial;           // [nq][gridDim.x][k] per-workgroup sorted lists
+    u64 *partial;           // [nq][gridDim.x * k] survivors of all workgroups, densely appended per query
+    u32 *partial_cnt;       // [nq] entries appended so far (zeroed before the launch)
     u32 pos_base;
 };
 
@@ -184,6 +185,23 @@ __device__ __forceinline__ gf4ptr group_ptr(const ScanArgs &a, u32 g) {
     int s = 0;
     while (s + 1 < a.nseg && g >= a.segs[s + 1].gstart) ++s;
     return as_global(a.segs[s].ptr) + (size_t)(g - a.segs[s].gstart) * a.K4 * GROUP_ROWS;
+}
+
+// End of a workgroup's scan: hand its (at most k) survivors of one query to the merge.  They are
+// appended densely to the query's global list (one atomicAdd reserves the range), unsorted unless the
+// workgroup holds more than k: the merge kernel filters and sorts anyway, and reads only what was
+// appended instead of gridDim.x fixed k-slot lists that are mostly padding.
+__device__ __forceinline__ void flush_survivors(const ScanArgs &a, int q, u64 *b, u32 n, int lane) {
+    if (n == 0) return;
+    if (n > (u32)a.k) {
+        wave_sort_desc(b, n, lane);
+        n = (u32)a.k;
+    }
+    u32 base = 0;
+    if (lane == 0) base = atomicAdd(&a.partial_cnt[q], n);
+    base = __shfl(base, 0);
+    u64 *out = a.partial + (size_t)q * gridDim.x * a.k + base;
+    for (u32 i = lane; i < n; i += 64) out[i] = b[i];
 }
 
 #define HAC_MFMA4(av, bv)                                                        \
@@ -326,10 +344,7 @@ __global__ __launch_bounds__(SCAN_WAVES * 64) void scan16_kernel(ScanArgs a) {
     for (int jj = w; jj < QTr; jj += SCAN_WAVES) {
         const u32 n = cnt[jj];
         u64 *b = cand + (size_t)jj * C;
-        if (n > 1) wave_sort_desc(b, n, lane);
-        u64 *out = a.partial + ((size_t)(q0 + jj) * gridDim.x + blockIdx.x) * a.k;
-        const u32 keep = n < (u32)a.k ? n : (u32)a.k;
-        for (u32 i = lane; i < (u32)a.k; i += 64) out[i] = i < keep ? b[i] : 0ull;
+        flush_survivors(a, q0 + jj, b, n, lane);
     }
 }
 
@@ -567,11 +582,7 @@ __global__ __launch_bounds__(W * 64) void scanq_kernel(ScanArgs a) {
     for (int jj = w; jj < NQr; jj += W) {
         u32 n = cnt[jj];
         if (n > (u32)C) n = (u32)C;
-        u64 *b = cand + (size_t)jj * C;
-        if (n > 1) wave_sort_desc(b, n, lane);
-        u64 *out = a.partial + ((size_t)(q0 + jj) * gridDim.x + blockIdx.x) * a.k;
-        const u32 keep = n < (u32)a.k ? n : (u32)a.k;
-        for (u32 i = lane; i < (u32)a.k; i += 64) out[i] = i < keep ? b[i] : 0ull;
+        flush_survivors(a, q0 + jj, cand + (size_t)jj * C, n, lane);
     }
 }
 
@@ -674,7 +685,8 @@ __global__ __launch_bounds__(256) void kth_select_kernel(const float *__restrict
 // Element (l, q, i) lives at lists[l*stride_l + q*stride_q + i].
 __global__ __launch_bounds__(MERGE_THREADS) void merge_keys_kernel(const u64 *__restrict__ lists, int L,
                                                                    size_t stride_l, size_t stride_q, int k, int Cm,
-                                                                   u64 *__restrict__ out, float *__restrict__ kth_out) {
+                                                                   u64 *__restrict__ out, float *__restrict__ kth_out,
+                                                                   const u32 *__restrict__ counts) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64 *buf = reinterpret_cast<u64 *>(smem);          // [Cm]
     u32 *cnt = reinterpret_cast<u32 *>(buf + Cm);      // [1]
@@ -686,14 +698,19 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_keys_kernel(const u64 *__
         *thrk = 0;
     }
     __syncthreads();
-    const long total = (long)L * k;
+    // slab mode: L lists of k slots.  dense mode (counts != null): counts[q] keys stored back to back.
+    const long total = counts ? (long)min((unsigned long long)counts[q], (unsigned long long)L * k) : (long)L * k;
     for (long base = 0; base < total; base += MERGE_THREADS) {
         const long idx = base + tid;
         u64 key = 0;
         if (idx < total) {
-            const long l = idx / k;
-            const int i = (int)(idx - l * k);
-            key = lists[(size_t)l * stride_l + q * stride_q + i];
+            if (counts) {
+                key = lists[q * stride_q + idx];
+            } else {
+                const long l = idx / k;
+                const int i = (int)(idx - l * k);
+                key = lists[(size_t)l * stride_l + q * stride_q + i];
+            }
         }
         if (key > *thrk) {
             const u32 pos = atomicAdd(cnt, 1u);
@@ -754,7 +771,7 @@ struct DeviceIndex {
     int64_t ntotal = 0;
     SegDesc *d_segs = nullptr;
     bool segs_dirty = true;
-    GrowBuf ws_partial, ws_seedkeys, ws_thr, ws_thrglob, ws_q, ws_qt, ws_keys, ws_D, ws_I, ws_stage[2];
+    GrowBuf ws_partial, ws_pcnt, ws_seedkeys, ws_thr, ws_thrglob, ws_q, ws_qt, ws_keys, ws_D, ws_I, ws_stage[2];
     void *h_stage[2] = {nullptr, nullptr};
     size_t h_stage_bytes = 0;
     // Small host<->device traffic (queries, results, segment table) always goes through
@@ -816,7 +833,7 @@ struct DeviceIndex {
         if (d_segs) (void)hipFree(d_segs);
         if (h_segs) (void)hipHostFree(h_segs);
         if (h_pin) (void)hipHostFree(h_pin);
-        for (GrowBuf *b : {&ws_partial, &ws_seedkeys, &ws_thr, &ws_thrglob, &ws_q, &ws_qt, &ws_keys, &ws_D, &ws_I, &ws_stage[0],
+        for (GrowBuf *b : {&ws_partial, &ws_pcnt, &ws_seedkeys, &ws_thr, &ws_thrglob, &ws_q, &ws_qt, &ws_keys, &ws_D, &ws_I, &ws_stage[0],
                            &ws_stage[1]})
             b->release();
         for (int i = 0; i < 2; ++i) {
@@ -1058,6 +1075,8 @@ struct DeviceIndex {
         a.thr_init = thr_init;
         a.thr_glob = (u32 *)ws_thrglob.p;
         a.partial = (u64 *)ws_partial.p;
+        a.partial_cnt = (u32 *)ws_pcnt.p;
+        HAC_HIP(hipMemsetAsync(ws_pcnt.p, 0, (size_t)nq * 4, st));
         a.pos_base = pos_base;
         HAC_HIP(hipMemsetAsync(ws_thrglob.p, 0, (size_t)pl.n_qtiles * pl.QT * 4, st));
         if (timed) {
@@ -1094,9 +1113,9 @@ struct DeviceIndex {
     }
 
     int run_merge(const Plan &pl, const u64 *lists, int L, size_t stride_l, size_t stride_q, int64_t nq, int k,
-                  u64 *out, float *kth_out, hipStream_t st) {
+                  u64 *out, float *kth_out, hipStream_t st, const u32 *counts = nullptr) {
         merge_keys_kernel<<<dim3((unsigned)nq), dim3(MERGE_THREADS), pl.lds_merge, st>>>(lists, L, stride_l, stride_q, k,
-                                                                                         pl.Cm, out, kth_out);
+                                                                                         pl.Cm, out, kth_out, counts);
         HAC_HIP(hipGetLastError());
         return HAC_OK;
     }
@@ -1115,6 +1134,7 @@ struct DeviceIndex {
         Plan pl;
         HAC_TRY(make_plan(nq, k, G, pl));
         HAC_TRY(ws_partial.reserve((size_t)nq * pl.P * k * 8));
+        HAC_TRY(ws_pcnt.reserve((size_t)nq * 4));
         HAC_TRY(ws_thrglob.reserve((size_t)pl.n_qtiles * pl.QT * 4));
         if (pl.kind == 1) {
             const long total = (long)pl.n_qtiles * K4 * pl.QT;
@@ -1156,7 +1176,8 @@ struct DeviceIndex {
             snprintf(last_plan, sizeof last_plan, "scan16_kernel<W=%d> grid=(%d,%d) QT=%d C=%d lds=%zu seed=%d", SCAN_WAVES, pl.P,
                      pl.n_qtiles, pl.QT, pl.C, pl.lds_scan, thr_init ? 1 : 0);
         HAC_TRY(run_scan(pl, q_dev, nq, k, 0, 1, G, thr_init, pos_base, pl.P, st, profiling));
-        HAC_TRY(run_merge(pl, (const u64 *)ws_partial.p, pl.P, (size_t)k, (size_t)pl.P * k, nq, k, keys_out, nullptr, st));
+        HAC_TRY(run_merge(pl, (const u64 *)ws_partial.p, pl.P, (size_t)k, (size_t)pl.P * k, nq, k, keys_out, nullptr, st,
+                          (const u32 *)ws_pcnt.p));
         return HAC_OK;
     }
 };
@@ -1310,7 +1331,7 @@ int hac_merge_keys_device(int device, const uint64_t *lists_dev, int n_lists, in
         attr_done[device] = true;
     }
     merge_keys_kernel<<<dim3((unsigned)nq), dim3(MERGE_THREADS), lds, (hipStream_t)hip_stream>>>(
-        (const u64 *)lists_dev, n_lists, (size_t)nq * k, (size_t)k, k, Cm, (u64 *)out_dev, nullptr);
+        (const u64 *)lists_dev, n_lists, (size_t)nq * k, (size_t)k, k, Cm, (u64 *)out_dev, nullptr, nullptr);
     HAC_HIP(hipGetLastError());
     return HAC_OK;
 }
