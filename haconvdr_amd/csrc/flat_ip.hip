@@ -589,7 +589,7 @@ __global__ __launch_bounds__(W * 64) void scanq_kernel(ScanArgs a) {
 // ------------------------------------------------------------------ threshold seeding
 // A lower bound of every query's final k-th score lets the scan kernels reject almost every row
 // with one compare.  It is the exact k-th largest score over an evenly strided sample of groups:
-//   sample_scores_kernel  best score of every sample group, [nq][n_groups] (same MFMA chain as the scans)
+//   sample_scores_kernel  best score of every 16-row quarter of the sample groups, [nq][4*n_groups]
 //   kth_select_kernel     per query, exact k-th largest of those maxima by 4-pass 8-bit radix select
 // The bound only filters; results never depend on it.
 __global__ __launch_bounds__(SCAN_WAVES * 64) void sample_scores_kernel(ScanArgs a, float *__restrict__ scores, u32 S) {
@@ -631,9 +631,9 @@ __global__ __launch_bounds__(SCAN_WAVES * 64) void sample_scores_kernel(ScanArgs
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    // one number per (query, group): the group's best score.  The k-th largest of these maxima is a lower
-    // bound of the k-th largest score overall (k distinct rows reach it) and, maxima of 64 being tightly
-    // distributed, a sharp one: ~1 % of the rows pass it at k = 100 with 256 sample groups.
+    // per (query, group): the best score of each 16-row quarter.  The k-th largest of these maxima is a
+    // lower bound of the k-th largest score overall (k distinct rows reach it) and, maxima being tightly
+    // distributed, a sharp one: well under 1 % of the rows pass it at k = 100 with ~250 sample groups.
     const long rem = a.n_rows - (long)g * GROUP_ROWS;
     float m = -INFINITY;
 #pragma unroll
@@ -641,9 +641,9 @@ __global__ __launch_bounds__(SCAN_WAVES * 64) void sample_scores_kernel(ScanArgs
         const int row = 16 * (rr >> 2) + 4 * (lane >> 4) + (rr & 3);
         if (row < rem) m = fmaxf(m, acc[rr]);
     }
-    m = fmaxf(m, __shfl_xor(m, 16));
-    m = fmaxf(m, __shfl_xor(m, 32));
-    if (lane < QTr) scores[(size_t)(q0 + lane) * S + item] = m;
+    // FOUR maxima per group (one per lane quarter = 16 of its rows): four times the sample points for
+    // the same MFMA work, and maxima of 16 are still tight enough for the k-th of them to sit high.
+    if (j < QTr) scores[(size_t)(q0 + j) * S + (size_t)item * 4 + (lane >> 4)] = m;
 }
 
 // thr[q] = k-th largest of scores[q][0..S) (NaN counts as -inf); -inf when fewer than k finite-or-inf entries
@@ -1150,9 +1150,10 @@ struct DeviceIndex {
         const float *thr_init = nullptr;
         // Threshold seeding: exact top-k of an evenly strided sample of groups gives a
         // lower bound of every query's final k-th score; it only filters, never decides.
-        const u32 n_sample = std::max<u32>(std::max<u32>(256u, G / 64u), 2u * (u32)k);
+        // sample ~1.6 % of the groups, at least 64 and enough for 2k maxima (4 per group)
+        const u32 n_sample = std::max<u32>(std::max<u32>(64u, G / 64u), ((u32)k + 1u) / 2u);
         if (G >= 4u * n_sample) {
-            const u32 S = n_sample;                                  // one maximum per sample group
+            const u32 S = 4u * n_sample;                             // four maxima per sample group
             HAC_TRY(ws_seedkeys.reserve((size_t)nq * S * 4));        // group maxima [nq][S]
             HAC_TRY(ws_thr.reserve((size_t)nq * 4));
             ScanArgs a{};
