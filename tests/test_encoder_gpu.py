@@ -131,3 +131,35 @@ def test_missing_weight_is_reported():
     with pytest.raises(HacError) as e:
         ANCEEncoder(n_layers=2).load_state_dict(sd)
     assert "output.dense.bias" in str(e.value)
+
+
+def test_from_pretrained_reads_checkpoint_dir(tmp_path):
+    """ANCE.from_pretrained(path) (:170) reads pytorch_model.bin with the keys roberta.*, embeddingHead.*,
+    norm.* (+ unused classifier.*): the mirror loads the same file."""
+    import torch
+    from haconvdr_amd.encoder import ANCEEncoder
+    sd = dict(state_dict(2))
+    sd["classifier.dense.weight"] = np.zeros((768, 768), np.float32)          # present in real checkpoints, unused
+    torch.save({k: torch.from_numpy(v) for k, v in sd.items()}, tmp_path / "pytorch_model.bin")
+    enc = ANCEEncoder.from_pretrained(str(tmp_path))
+    g = np.load([p for p in GOLD if "l2_full384" in p][0])
+    out = enc(g["ids"].astype(np.int32), g["mask"].astype(np.int32))
+    np.testing.assert_array_equal(out, encoder(2)(g["ids"].astype(np.int32), g["mask"].astype(np.int32)))
+
+
+def test_get_test_query_embedding_loop():
+    """Mirror of get_test_query_embedding's loop: same batches in, (embeddings, ids) out; batching by 4 (the
+    reference's default) must equal one big call."""
+    import torch
+    from haconvdr_amd.queries import get_test_query_embedding
+    g = np.load([p for p in GOLD if "l2_mixed" in p][0])
+    enc = encoder(2)
+    ids = torch.from_numpy(g["ids"].astype(np.int64))
+    mask = torch.from_numpy(g["mask"].astype(np.int64))
+    loader = [{"bt_sample_ids": [f"q{b}_{i}" for i in range(4)], "bt_conv_qa": ids[b:b + 4], "bt_conv_qa_mask": mask[b:b + 4]}
+              for b in (0, 4)]
+    emb, e2id = get_test_query_embedding(enc, loader, "convqa")
+    assert emb.dtype == np.float32 and emb.shape == (8, 768) and e2id == [f"q{b}_{i}" for b in (0, 4) for i in range(4)]
+    np.testing.assert_array_equal(emb, enc(g["ids"].astype(np.int32), g["mask"].astype(np.int32)))
+    with pytest.raises(ValueError):
+        get_test_query_embedding(enc, loader, "nope")
