@@ -54,6 +54,7 @@ struct SeqInfo {
     int *off;     // [B+1] first packed row of each sequence; off[B] = total rows
     int *pos;     // [B][L] position ids (HF rule), valid for t < len
     int *err;     // [1] != 0 if some mask is not a prefix mask / empty
+    int *nb;      // [1] number of sequences (device copy; row count of the CLS-only tail)
 };
 
 // one workgroup per sequence: len = sum(mask), prefix check, HF position ids
@@ -109,6 +110,7 @@ __global__ void seq_offsets_kernel(SeqInfo s, int B) {
             acc += s.len32[b];
         }
         s.off[B] = acc;
+        *s.nb = B;
     }
 }
 
@@ -439,6 +441,7 @@ struct AttnArgs {
     long ldvt;
     bf16 *ctx;               // [Mp][768]
     SeqInfo s;
+    int cls_only;            // last layer: only the query block holding <s> is needed (models.py:56 takes [:,0])
 };
 
 // Workgroup = 4 waves = 256 query rows of one (sequence, head); each wave owns TWO 32-row query blocks,
@@ -470,7 +473,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a) {
     }
     __syncthreads();  // hipcc drains the LDS-DMA here
     const int q0 = qbase + w * 64;
-    if (q0 >= len32) return;  // no barriers below
+    if (q0 >= len32 || (a.cls_only && w != 0)) return;  // no barriers below
 
     // Q^T fragments (B operand of S^T = K.Q^T): lane (q = r, half hh) holds q[16*ks + 8*hh .. +8)
     bf16x8 qf[2][4];
@@ -578,7 +581,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a) {
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        if (q0 + u * 32 >= len32) break;  // second block past the sequence: computed on foreign rows, never stored
+        if (q0 + u * 32 >= len32 || (a.cls_only && u)) break;  // past the sequence (computed on foreign rows) or not needed
         const float l = lsum[u] + __shfl_xor(lsum[u], 32);
         const float inv = 1.0f / l;  // lane r holds 1/l of query r (both halves)
         // O tile t: lane column = d = 32t + r, register e <-> query row (e&3) + 8*(e>>2) + 4*hh
@@ -593,15 +596,36 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a) {
     }
 }
 
-// ------------------------------------------------------------------ ANCE head: out[b] = LN(W_h . x[off[b]] + b_h)   (fp32)
-__global__ __launch_bounds__(256) void cls_head_kernel(const float *__restrict__ x, SeqInfo s, const float *__restrict__ Wh,
+// Last layer: everything after attention is only needed for the <s> row of each sequence
+// (masked_mean_or_first with use_mean=False, src/models.py:52-56): gather those B rows into compact
+// matrices and run out-proj, LN, FFN, LN on B rows instead of T.
+__global__ __launch_bounds__(256) void gather_cls_kernel(const bf16 *__restrict__ ctx, const float *__restrict__ x, SeqInfo s, int B,
+                                                         bf16 *__restrict__ ctx_c, float *__restrict__ x_c) {
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (b < B) {
+        const size_t row = (size_t)s.off[b];
+        for (int i = tid; i < H; i += 256) {
+            ctx_c[(size_t)b * H + i] = ctx[row * H + i];
+            x_c[(size_t)b * H + i] = x[row * H + i];
+        }
+    } else {  // padding rows of the compact matrices feed the GEMM tiles: keep them finite
+        for (int i = tid; i < H; i += 256) {
+            ctx_c[(size_t)b * H + i] = (bf16)0.f;
+            x_c[(size_t)b * H + i] = 0.f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ ANCE head: out[b] = LN(W_h . x[row_b] + b_h)   (fp32)
+__global__ __launch_bounds__(256) void cls_head_kernel(const float *__restrict__ x, SeqInfo s, int compact, const float *__restrict__ Wh,
                                                        const float *__restrict__ bh, const float *__restrict__ gamma,
                                                        const float *__restrict__ beta, float eps, float *__restrict__ out) {
     __shared__ float xs[H];
     __shared__ float es[H];
     __shared__ float red[8];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const float *xr = x + (size_t)s.off[b] * H;
+    const float *xr = x + (size_t)(compact ? b : s.off[b]) * H;
     for (int i = tid; i < H; i += 256) xs[i] = xr[i];
     __syncthreads();
     const bool bad = *s.err != 0;
@@ -671,7 +695,7 @@ struct hac_encoder {
     float *wh = nullptr, *bh = nullptr, *ng = nullptr, *nb = nullptr;
     bool finalized = false;
     // workspace
-    GrowBuf ws_x, ws_xb, ws_q, ws_k, ws_vt, ws_ctx, ws_y, ws_h, ws_seq, ws_ids, ws_mask, ws_out;
+    GrowBuf ws_x, ws_xb, ws_q, ws_k, ws_vt, ws_ctx, ws_y, ws_h, ws_seq, ws_ids, ws_mask, ws_out, ws_cls;
     void *h_pin = nullptr;
     size_t h_pin_bytes = 0;
     // profiling (bench): events around the layer stack of each forward
@@ -723,6 +747,7 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
     s.len32 = p + B;
     s.off = p + 2 * B;          // B+1 entries
     s.err = p + 3 * B + 2;
+    s.nb = p + 3 * B + 3;
     s.pos = p + 3 * B + 4;
     HAC_HIP(hipMemsetAsync(s.err, 0, 4, st));
     seq_prep_kernel<IT><<<dim3(B), dim3(512), 0, st>>>(ids, mask, L, s, c.pad_token_id);
@@ -757,25 +782,51 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
         }
         HAC_HIP(hipEventRecord(e->ev_pool[e->ev_used].first, st));
     }
+    // compact buffers of the CLS-only tail of the last layer
+    const long Mc = ((long)B + MT - 1) / MT * MT;
+    HAC_TRY(e->ws_cls.reserve((size_t)Mc * (H * 2 + H * 4 * 3 + H * 2 + FF * 2)));
+    bf16 *ctx_c = (bf16 *)e->ws_cls.p;
+    float *x_c = (float *)(ctx_c + Mc * H);
+    float *y_c = x_c + Mc * H;
+    float *x2_c = y_c + Mc * H;
+    bf16 *xb_c = (bf16 *)(x2_c + Mc * H);
+    bf16 *h_c = xb_c + Mc * H;
     for (int li = 0; li < c.n_layers; ++li) {
         const LayerW &w = e->layers[li];
+        const bool last = (li == c.n_layers - 1);
         GemmArgs g{};
         g.total_rows = total;
         // QKV
         g.A = xb; g.W = w.wqkv; g.bias = w.bqkv; g.N = 3 * H; g.K = H; g.q = q; g.k = k; g.vt = vt; g.ldvt = ldvt;
         HAC_GEMM(EPI_QKV, 3 * H);
-        AttnArgs a{q, k, vt, ldvt, ctx, s};
-        attention_kernel<<<dim3((L32 + 255) / 256, NH, B), dim3(256), (size_t)L32 * 128, st>>>(a);
-        // attention output projection + residual, LN
-        g.A = ctx; g.W = w.wo; g.bias = w.bo; g.N = H; g.K = H; g.resid = x; g.y = y;
-        HAC_GEMM(EPI_RESID, H);
-        ln_rows_kernel<<<dim3((unsigned)(Mp / 4)), dim3(256), 0, st>>>(y, total, w.ln1g, w.ln1b, c.ln_eps, x, xb);
-        // FFN
-        g.A = xb; g.W = w.w1; g.bias = w.b1; g.N = FF; g.K = H; g.h = h;
-        HAC_GEMM(EPI_GELU, FF);
-        g.A = h; g.W = w.w2; g.bias = w.b2; g.N = H; g.K = FF; g.resid = x; g.y = y;
-        HAC_GEMM(EPI_RESID, H);
-        ln_rows_kernel<<<dim3((unsigned)(Mp / 4)), dim3(256), 0, st>>>(y, total, w.ln2g, w.ln2b, c.ln_eps, x, xb);
+        AttnArgs a{q, k, vt, ldvt, ctx, s, last ? 1 : 0};
+        attention_kernel<<<dim3(last ? 1 : (L32 + 255) / 256, NH, B), dim3(256), (size_t)L32 * 128, st>>>(a);
+        if (!last) {
+            // attention output projection + residual, LN
+            g.A = ctx; g.W = w.wo; g.bias = w.bo; g.N = H; g.K = H; g.resid = x; g.y = y;
+            HAC_GEMM(EPI_RESID, H);
+            ln_rows_kernel<<<dim3((unsigned)(Mp / 4)), dim3(256), 0, st>>>(y, total, w.ln1g, w.ln1b, c.ln_eps, x, xb);
+            // FFN
+            g.A = xb; g.W = w.w1; g.bias = w.b1; g.N = FF; g.K = H; g.h = h;
+            HAC_GEMM(EPI_GELU, FF);
+            g.A = h; g.W = w.w2; g.bias = w.b2; g.N = H; g.K = FF; g.resid = x; g.y = y;
+            HAC_GEMM(EPI_RESID, H);
+            ln_rows_kernel<<<dim3((unsigned)(Mp / 4)), dim3(256), 0, st>>>(y, total, w.ln2g, w.ln2b, c.ln_eps, x, xb);
+        } else {
+            // only the <s> row of every sequence continues (B rows instead of T): same kernels, compact matrices
+            gather_cls_kernel<<<dim3((unsigned)Mc), dim3(256), 0, st>>>(ctx, x, s, B, ctx_c, x_c);
+            const size_t lds_s = (size_t)4 * 128 * 128 + (size_t)4 * 4096;
+            const dim3 grid_s((unsigned)(e->n_cu * 2)), blk_s(256);
+            g.total_rows = s.nb;
+            g.A = ctx_c; g.W = w.wo; g.bias = w.bo; g.N = H; g.K = H; g.resid = x_c; g.y = y_c;
+            gemm_bf16_nt_kernel<EPI_RESID, 2><<<grid_s, blk_s, lds_s, st>>>(g);
+            ln_rows_kernel<<<dim3((unsigned)(Mc / 4)), dim3(256), 0, st>>>(y_c, s.nb, w.ln1g, w.ln1b, c.ln_eps, x2_c, xb_c);
+            g.A = xb_c; g.W = w.w1; g.bias = w.b1; g.N = FF; g.K = H; g.h = h_c;
+            gemm_bf16_nt_kernel<EPI_GELU, 2><<<grid_s, blk_s, lds_s, st>>>(g);
+            g.A = h_c; g.W = w.w2; g.bias = w.b2; g.N = H; g.K = FF; g.resid = x2_c; g.y = y_c;
+            gemm_bf16_nt_kernel<EPI_RESID, 2><<<grid_s, blk_s, lds_s, st>>>(g);
+            ln_rows_kernel<<<dim3((unsigned)(Mc / 4)), dim3(256), 0, st>>>(y_c, s.nb, w.ln2g, w.ln2b, c.ln_eps, x_c, xb_c);
+        }
         HAC_HIP(hipGetLastError());
     }
 #undef HAC_GEMM
@@ -783,7 +834,7 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
         HAC_HIP(hipEventRecord(e->ev_pool[e->ev_used].second, st));
         ++e->ev_used;
     }
-    cls_head_kernel<<<dim3(B), dim3(256), 0, st>>>(x, s, e->wh, e->bh, e->ng, e->nb, 1e-5f, out_dev);
+    cls_head_kernel<<<dim3(B), dim3(256), 0, st>>>(x_c, s, 1, e->wh, e->bh, e->ng, e->nb, 1e-5f, out_dev);
     HAC_HIP(hipGetLastError());
     return HAC_OK;
 }
@@ -848,7 +899,7 @@ void hac_encoder_destroy(hac_encoder *e) {
             if (p) (void)hipFree(p);
     for (auto &l : e->layers)
         if (l.bqkv) (void)hipFree(l.bqkv);
-    for (GrowBuf *b : {&e->ws_x, &e->ws_xb, &e->ws_q, &e->ws_k, &e->ws_vt, &e->ws_ctx, &e->ws_y, &e->ws_h, &e->ws_seq, &e->ws_ids, &e->ws_mask, &e->ws_out})
+    for (GrowBuf *b : {&e->ws_x, &e->ws_xb, &e->ws_q, &e->ws_k, &e->ws_vt, &e->ws_ctx, &e->ws_y, &e->ws_h, &e->ws_seq, &e->ws_ids, &e->ws_mask, &e->ws_out, &e->ws_cls})
         b->release();
     if (e->h_pin) (void)hipHostFree(e->h_pin);
     for (auto &ev : e->ev_pool) {

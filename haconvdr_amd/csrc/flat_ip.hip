@@ -1020,6 +1020,10 @@ struct DeviceIndex {
                     best_pad = pad;
                 }
             }
+            if (const char *fn = getenv("HAC_SCANQ_NT")) {   // tuning experiments only
+                const int nt = atoi(fn);
+                if (nt >= 1 && nt <= 4 && scanq_lds(32 * nt, C2) <= LDS_LIMIT) best_nt = nt;
+            }
             if (best_nt) {
                 pl.kind = 1;
                 pl.NT = best_nt;
@@ -1046,7 +1050,7 @@ struct DeviceIndex {
         per_cu = std::max(1, std::min(per_cu, pl.kind == 1 ? 2 : 4));
         const long resident = (long)n_cu * per_cu;
         long P = std::max<long>(1, resident / pl.n_qtiles);
-        if (P >= 8) P = P / 8 * 8;  // same-row workgroups of different query tiles share an XCD (L2)
+        if (P >= 8 && !getenv("HAC_SCAN_NO_P8")) P = P / 8 * 8;  // same-row workgroups of different query tiles share an XCD (L2)
         const long maxP = (n_items + pl.W - 1) / pl.W;
         P = std::max<long>(1, std::min(P, maxP));
         pl.P = (int)P;
