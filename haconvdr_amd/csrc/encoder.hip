@@ -255,8 +255,7 @@ __device__ __forceinline__ float gelu_erf(float x) { return gelu_erf2((f2v){x, x
 template <int EPI, int TMT>
 __global__ __launch_bounds__(TMT * 128, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
     // LDS: two stages of {A tile BMx64, W tile BNx64} bf16 + one 4 KiB transpose patch per wave.
-    // 16-byte chunk c of row r lives at r*128 + ((c ^ (r & 7)) << 4): the 8 rows of a ds_read_b128 lane
-    // group hit 8 distinct slots.  Tiles arrive by LDS-DMA (global_load_lds_dwordx4, 1 KiB = 8 rows per
+    // 16-byte chunk c of row r lives at r*128 + ((c ^ ((r >> 1) & 7)) << 4): conflict-free ds_read_b128.  Tiles arrive by LDS-DMA (global_load_lds_dwordx4, 1 KiB = 8 rows per
     // wave-instruction, no VGPRs, no ds_write); the DMA destination is lane-linear, so the swizzle is
     // applied to the per-lane SOURCE address (chunk (lane&7) ^ (lane>>3) of row lane>>3).
     constexpr int BM = 64 * TMT, BN = BM;
@@ -280,26 +279,33 @@ __global__ __launch_bounds__(TMT * 128, 2) void gemm_bf16_nt_kernel(GemmArgs g) 
 
     typedef const __attribute__((address_space(1))) void *gvp;
     typedef __attribute__((address_space(3))) void *lvp;
-    const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
-    const size_t lane_src = (size_t)(w * 32 + srow) * K + schunk * 8;
+    // swizzle f(row) = (row >> 1) & 7: two 128-B rows share a 256-B bank row, so the rows of one
+    // ds_read_b128 lane group (e.g. 0-3, 12-15, 20-27) need distinct f among rows of equal parity;
+    // (row & 7) repeats (rows 12 and 20) and costs a 2-way conflict on every fragment read.
+    // Row of DMA piece i of wave w: w*32 + i*8 + (lane>>3)  ->  f = ((i&1)*4 + (lane>>4)) & 7.
+    const int srow = lane >> 3;
+    const int sch_even = (lane & 7) ^ (srow >> 1), sch_odd = sch_even ^ 4;
+    const size_t lane_src_e = (size_t)(w * 32 + srow) * K + sch_even * 8;
+    const size_t lane_src_o = (size_t)(w * 32 + srow) * K + sch_odd * 8;
     auto stage = [&](int buf, int t, int kt) {
         const int m0s = (t / nx) * BM, n0s = (t % nx) * BN;
-        const bf16 *gA = g.A + (size_t)m0s * K + lane_src + kt * BK;
-        const bf16 *gW = g.W + (size_t)n0s * K + lane_src + kt * BK;
+        const bf16 *gA = g.A + (size_t)m0s * K + kt * BK;
+        const bf16 *gW = g.W + (size_t)n0s * K + kt * BK;
         unsigned char *sb = smem + buf * STAGE + w * 4096;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds((gvp)(gA + (size_t)i * 8 * K), (lvp)(sb + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gvp)(gW + (size_t)i * 8 * K), (lvp)(sb + BM * 128 + i * 1024), 16, 0, 0);
+            const size_t ls = ((i & 1) ? lane_src_o : lane_src_e) + (size_t)i * 8 * K;
+            __builtin_amdgcn_global_load_lds((gvp)(gA + ls), (lvp)(sb + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gvp)(gW + ls), (lvp)(sb + BM * 128 + i * 1024), 16, 0, 0);
         }
     };
-    // fragment byte offsets inside a stage, per k-step: row*128 + ((2*ks+hh) ^ (row&7))*16
+    // fragment byte offsets inside a stage, per k-step: row*128 + ((2*ks+hh) ^ f(row))*16
     int aoff[TMT], woff[2];
 #pragma unroll
     for (int t = 0; t < TMT; ++t) aoff[t] = (wm * (32 * TMT) + t * 32 + r) * 128;
 #pragma unroll
     for (int t = 0; t < 2; ++t) woff[t] = BM * 128 + (wn * 64 + t * 32 + r) * 128;
-    const int sw = r & 7;  // (row & 7) is the same for every fragment row of a lane
+    const int sw = (r >> 1) & 7;  // f(row) is the same for every fragment row of a lane (rows differ by multiples of 32)
     float *patch = reinterpret_cast<float *>(smem + 2 * STAGE) + w * 1024;  // [16 rows][64 cols] fp32, wave-private
 
     int cur = 0;
@@ -451,7 +457,7 @@ struct AttnArgs {
 // Measured before this structure: every wave fetched K twice and V once from L2 per key block and the
 // kernel ran at the L2's ~6 TB/s.
 __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // K image: row*128 + ((c ^ (row&7)) << 4)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // K image: row*128 + ((c ^ ((row>>1)&7)) << 4)
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.z, head = blockIdx.y;
@@ -466,7 +472,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a) {
     {   // stage K[base .. base+len32)[head*64 .. +64) -> LDS, 8 rows (1 KiB) per wave-instruction
         typedef const __attribute__((address_space(1))) void *gvp;
         typedef __attribute__((address_space(3))) void *lvp;
-        const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
+        // same swizzle as the GEMM image: f(row) = (row >> 1) & 7; rows of this wave's pieces are
+        // r8*8 + (lane>>3) with r8 = w (mod 4), so f = ((w&1)*4 + (lane>>4)) & 7
+        const int srow = lane >> 3, schunk = (lane & 7) ^ ((((w & 1) << 2) + (srow >> 1)) & 7);
         const bf16 *src = a.k + (base + srow) * H + head * DH + schunk * 8;
         for (int r8 = w; r8 * 8 < len32; r8 += 4)
             __builtin_amdgcn_global_load_lds((gvp)(src + (size_t)r8 * 8 * H), (lvp)(smem + r8 * 1024), 16, 0, 0);
@@ -484,7 +492,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a) {
         for (int ks = 0; ks < 4; ++ks) qf[u][ks] = *reinterpret_cast<const bf16x8 *>(qrow + ks * 16);
     }
     const unsigned char *krow = smem + r * 128;
-    const int sw = r & 7;
+    const int sw = (r >> 1) & 7;
 
     // pass 1: row maxima.  S^T tile: lane column = query r, register e <-> key (e&3) + 8*(e>>2) + 4*hh
     float mx[2] = {-INFINITY, -INFINITY};
