@@ -330,3 +330,40 @@ def test_scan16_and_scanq_agree(oracle, monkeypatch):
     oD, oI = oracle.flat_ip_search(x, q, 100)
     for D, I in ((D1, I1), (D2, I2), (D3, I3)):
         assert_same(D, I, oD, oI)
+
+
+def test_cfg3_block_size_properties(oracle):
+    """One TopiOCQA-scale block (BASELINE.json configs[2]: 25M passages in 8 blocks = 3.125M rows = 9.6 GB):
+    sortedness, split invariance against two half indexes, and bit-exact agreement with the oracle on four
+    queries, in both kernel regimes (16 queries: HBM-bound scan16; 64 queries: scanq)."""
+    import torch
+    from haconvdr_amd.index import FlatIPIndex, merge_keys, keys_to_results
+    N, K = 3_125_000, 100
+    gen = torch.Generator(device="cuda").manual_seed(0xC0FFEE + 3)
+    idx, h1, h2 = FlatIPIndex(768), FlatIPIndex(768), FlatIPIndex(768)
+    host = []
+    for i in range(0, N, 625_000):
+        xb = torch.randn((625_000, 768), generator=gen, device="cuda")
+        xb = (xb - xb.mean(1, keepdim=True)) / xb.std(1, unbiased=False, keepdim=True)
+        idx.add_tensor(xb)
+        (h1 if i < 1_250_000 else h2).add_tensor(xb)
+        host.append(xb.cpu().numpy())
+        del xb
+    torch.cuda.synchronize()
+    assert idx.ntotal == N and h1.ntotal == 1_250_000 and h2.ntotal == 1_875_000
+    q = torch.randn((64, 768), generator=gen, device="cuda")
+    q = (q - q.mean(1, keepdim=True)) / q.std(1, unbiased=False, keepdim=True)
+    xh = np.concatenate(host)
+    del host
+    sel = [0, 1, 2, 63]
+    oD, oI = oracle.flat_ip_search(xh, q[sel].cpu().numpy(), K)
+    for nq in (16, 64):
+        D, I = idx.search_tensor(q[:nq], K)
+        assert bool((D[:, :-1] >= D[:, 1:]).all()) and int(I.min()) >= 0 and int(I.max()) < N
+        k1 = h1.search_keys_tensor(q[:nq], K, pos_base=0)
+        k2 = h2.search_keys_tensor(q[:nq], K, pos_base=1_250_000)
+        D2, I2 = keys_to_results(merge_keys(torch.stack([k1, k2])))
+        assert torch.equal(I2, I) and torch.equal(D2, D)
+        s = [j for j in sel if j < nq]
+        np.testing.assert_array_equal(I[s].cpu().numpy(), oI[:len(s)])
+        np.testing.assert_array_equal(D[s].cpu().numpy(), oD[:len(s)])
