@@ -245,12 +245,33 @@ def main():
                   "layer_stack_ms": round(stack_ms, 3), "achieved_TFLOPs": round(fl / (stack_ms * 1e-3) / 1e12, 1),
                   "mfma_bf16_frac_of_2.5PF": round(fl / (stack_ms * 1e-3) / 2.5e15, 4), "dtype": "bf16 MFMA operands, fp32 accumulate/LN/softmax",
                   "weights": "synthetic N(0,0.02) RoBERTa-base"}
+        # passages (BASELINE configs[4] shape: L=384): fully padded = what the reference computes, and
+        # varlen = only the real tokens (lens ~ clipped N(180, 80) in [8, 384])
+        Bp, Lp = 1000, 384
+        ptok, _ = synth.token_batch(0xD0C + rank, Bp, Lp, fixed_len=Lp)
+        plens = np.clip(np.rint(180.0 + 80.0 * synth.normal(0x1E45 + rank, (Bp,))), 8, Lp).astype(np.int64)
+        pid_t = torch.from_numpy(ptok.astype(np.int64)).to(dev)
+        full_mask = torch.ones_like(pid_t)
+        var_mask = (torch.arange(Lp, device=dev)[None, :] < torch.from_numpy(plens).to(dev)[:, None]).to(torch.int64)
+        pres = {}
+        for name, m in (("padded", full_mask), ("varlen", var_mask)):
+            for _ in range(2):
+                enc(pid_t, m)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                enc(pid_t, m)
+            torch.cuda.synchronize()
+            pres[name] = Bp / ((time.perf_counter() - t1) / 3)
+        encode["passages_L384"] = {"docs_per_sec_per_gpu_padded": round(pres["padded"], 1),
+                                   "docs_per_sec_per_gpu_varlen": round(pres["varlen"], 1),
+                                   "mean_len_varlen": round(float(plens.mean()), 1), "batch": Bp}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             # CPU baseline of the encoder: the fp32 oracle (torch CPU ops, all host cores) on a bounded sample
             from oracle import ance_oracle
             sd_cpu = synth.ance_state_dict(0xA11CE, 12, rich=False)
-            n_s = 16
-            torch.set_num_threads(len(os.sched_getaffinity(0)))
+            n_s = 8
+            torch.set_num_threads(min(64, len(os.sched_getaffinity(0))))   # torch CPU GEMMs stop scaling well before 128+ threads
             tp = time.perf_counter()
             ref = ance_oracle.ance_forward(sd_cpu, tok[:n_s].astype(np.int64), np.ones((n_s, Lq), np.int64))
             tcpu = time.perf_counter() - tp
