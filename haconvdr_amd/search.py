@@ -9,25 +9,24 @@ block resident in HBM and running ONE exact top-k over all of them, with the
 """
 import logging
 import os
-import pickle
 
 import numpy as np
 
 logger = logging.getLogger(__name__)
 
 
-def iter_embedding_blocks(passage_embeddings_dir, passage_block_num):
+def iter_embedding_blocks(passage_embeddings_dir, passage_block_num, mmap=True):
     """Yield (emb float32 [n,768], ids int64 [n]) for block 0,1,… ; stops at the first
-    block that cannot be loaded, like the reference's bare ``except: break`` (:94-95)."""
+    block that cannot be loaded, like the reference's bare ``except: break`` (:94-95).
+    mmap=True maps the pickled ndarray payload in place (haconvdr_amd.passages) instead of copying
+    the 7.7 GB block through ``pickle.load`` — the reference's dominant wall time at search."""
+    from .passages import read_embedding_block
     for block_id in range(passage_block_num):
         try:
-            with open(os.path.join(passage_embeddings_dir, f"passage_emb_block_{block_id}.pb"), "rb") as h:
-                emb = pickle.load(h)
-            with open(os.path.join(passage_embeddings_dir, f"passage_embid_block_{block_id}.pb"), "rb") as h:
-                ids = pickle.load(h)
+            emb, ids = read_embedding_block(passage_embeddings_dir, block_id, mmap=mmap)
         except Exception:
             break
-        yield np.asarray(emb), np.asarray(ids)
+        yield emb, np.asarray(ids)
 
 
 def search_blocks(index, blocks, query_embeddings, topN):
@@ -75,3 +74,35 @@ def search_one_by_one(args, passage_embeddings_dir, index, query_embeddings, top
     merged_D, merged_I = search_blocks(index, blocks, query_embeddings, topN)
     logger.info(merged_I.shape)
     return merged_D, merged_I
+
+
+class ResidentCorpus:
+    """All passage blocks of a directory resident in HBM, searched many times (the reference reloads
+    every block for every evaluation run, :77-123).  Same result contract as search_one_by_one."""
+
+    def __init__(self, passage_embeddings_dir, passage_block_num, index=None, device=0):
+        import torch
+        from .index import FlatIPIndex
+        self.index = index if index is not None else FlatIPIndex(768, devices=(device,))
+        self.index.reset()
+        ids, self.sizes = [], []
+        for emb, bid in iter_embedding_blocks(passage_embeddings_dir, passage_block_num):
+            self.index.add(emb)
+            ids.append(np.asarray(bid, dtype=np.int64))
+            self.sizes.append(len(bid))
+        if not ids:
+            raise ValueError("no passage block could be loaded")
+        self.dev = torch.device("cuda", self.index.devices[0])
+        self.id_map = torch.from_numpy(np.concatenate(ids)).to(self.dev)
+
+    @property
+    def ntotal(self):
+        return self.index.ntotal
+
+    def search(self, query_embeddings, topN):
+        """query_embeddings: float32 [nq,768] (numpy or CUDA tensor) -> (D float64 [nq,topN], I int64 [nq,topN])."""
+        import torch
+        q = query_embeddings if isinstance(query_embeddings, torch.Tensor) else torch.from_numpy(
+            np.ascontiguousarray(query_embeddings, dtype=np.float32))
+        D, I = self.index.search_tensor(q.to(self.dev), topN, id_map=self.id_map)
+        return D.cpu().numpy().astype(np.float64), I.cpu().numpy()

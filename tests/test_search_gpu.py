@@ -367,3 +367,19 @@ def test_cfg3_block_size_properties(oracle):
         s = [j for j in sel if j < nq]
         np.testing.assert_array_equal(I[s].cpu().numpy(), oI[:len(s)])
         np.testing.assert_array_equal(D[s].cpu().numpy(), oD[:len(s)])
+
+
+def test_resident_corpus_many_searches(tmp_path, oracle):
+    """Blocks loaded once (zero-copy mmap of the pickled payload), searched repeatedly."""
+    from haconvdr_amd.passages import write_embedding_block
+    from haconvdr_amd.search import ResidentCorpus
+    x, q, ids = cases.search_case_inputs("gauss", 4711, 5000, 12)
+    for b, (lo, hi) in enumerate(((0, 1800), (1800, 3600), (3600, 5000))):
+        write_embedding_block(str(tmp_path), b, x[lo:hi], ids[lo:hi])
+    rc = ResidentCorpus(str(tmp_path), passage_block_num=10)
+    assert rc.ntotal == 5000
+    oD, oI = oracle.flat_ip_search(x, q, 100)
+    for sl in (slice(0, 12), slice(3, 5)):
+        D, I = rc.search(q[sl], 100)
+        np.testing.assert_array_equal(I, ids[oI[sl]])
+        np.testing.assert_array_equal(D, oD[sl].astype(np.float64))
