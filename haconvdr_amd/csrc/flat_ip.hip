@@ -649,6 +649,7 @@ __global__ __launch_bounds__(SCAN_WAVES * 64) void sample_scores_kernel(ScanArgs
 // thr[q] = k-th largest of scores[q][0..S) (NaN counts as -inf); -inf when fewer than k finite-or-inf entries
 __global__ __launch_bounds__(256) void kth_select_kernel(const float *__restrict__ scores, u32 S, int k, float *__restrict__ thr) {
     __shared__ u32 hist[256];
+    __shared__ u32 wtot[4];
     __shared__ u32 sel_prefix, sel_k;
     const int tid = threadIdx.x;
     const float *src = scores + (size_t)blockIdx.x * S;
@@ -663,15 +664,26 @@ __global__ __launch_bounds__(256) void kth_select_kernel(const float *__restrict
             if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-            u32 cum = 0;
-            int b = 255;
-            for (; b > 0; --b) {
-                if (cum + hist[b] >= kk) break;
-                cum += hist[b];
+        {   // bin b holds the kk-th largest key iff  above(b) < kk <= above(b) + hist[b],  above(b) = sum of bins > b.
+            // Parallel suffix sum over the 256 bins (one per thread): wave scan + cross-wave offsets.
+            const u32 hcnt = hist[tid];
+            u32 inc = hcnt;  // inclusive suffix sum within the wave (towards higher lanes)
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const u32 v = __shfl_down(inc, o);
+                if ((tid & 63) + o < 64) inc += v;
             }
-            sel_prefix = prefix | ((u32)b << shift);
-            sel_k = kk - cum;
+            if ((tid & 63) == 0) wtot[tid >> 6] = inc;   // total of this wave's 64 bins
+            __syncthreads();
+            u32 above = inc - hcnt;
+            for (int ww = (tid >> 6) + 1; ww < 4; ++ww) above += wtot[ww];
+            const bool hit = above < kk && kk <= above + hcnt;
+            // fewer than kk candidates in total: fall to bin 0 (the caller reports -inf for prefix 0 chains)
+            const bool none = (tid == 0) && (above + hcnt < kk);
+            if (hit || none) {
+                sel_prefix = prefix | ((u32)tid << shift);
+                sel_k = hit ? kk - above : 1u;
+            }
         }
         __syncthreads();
         prefix = sel_prefix;
