@@ -16,6 +16,7 @@
 //   * attention: one wave = 32 query rows of one (sequence, head); S^T = K.Q^T so the query sits
 //     on the lane, softmax statistics are lane-local; the S^T accumulator is converted in place
 //     into the A operand of P.V (no LDS); V comes pre-transposed from the QKV epilogue.
+#include <type_traits>
 #include "hac_common.h"
 
 #include <cmath>
@@ -217,15 +218,14 @@ struct GemmArgs {
     int N, K;
     const int *total_rows;  // device: rows in use; tiles starting beyond it exit
     // epilogue outputs
-    bf16 *q, *k, *vt;     // EPI_QKV: q,k [Mp][768]; vt [768][ldvt]
-    long ldvt;
+    bf16 *q, *k, *v16;    // EPI_QKV: q,k [Mp][768]; v16 [Mp/16][768][16] (16-key groups, see attention_kernel)
     const float *resid;   // EPI_RESID: [Mp][768] fp32
     float *y;             // EPI_RESID: [Mp][768] fp32
     bf16 *h;              // EPI_GELU: [Mp][N] bf16
 };
 
 // exact-erf GELU (hidden_act = "gelu").  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32
-// rounding level and 4 orders below the bf16 grid the result is stored on): 1 rcp + 1 exp2 + 7 fma
+// rounding level and 4 orders below the bf16 grid the result is stored on): 1 v_rcp + 1 v_exp + 7 fma
 // instead of ocml erff's branchy ~30 instructions on 400 M elements per FFN.  Evaluated on PAIRS so
 // that hipcc emits v_pk_fma_f32 / v_pk_mul_f32 (half the VALU issue slots; no MFMA runs beside the epilogue).
 typedef float f2v __attribute__((ext_vector_type(2)));
@@ -239,7 +239,7 @@ __device__ __forceinline__ f2v gelu_erf2(f2v x) {
     p = p * t + (-0.284496736f);
     p = p * t + 0.254829592f;
     const f2v zz = z * z * (-1.44269504088896341f);
-    const f2v ex = {exp2f(zz.x), exp2f(zz.y)};
+    const f2v ex = {__builtin_amdgcn_exp2f(zz.x), __builtin_amdgcn_exp2f(zz.y)};  // raw v_exp_f32: zz <= 0, underflow to 0 is fine
     const f2v e = 1.0f - p * t * ex;                       // erf(|x|/sqrt2)
     const f2v se = {copysignf(e.x, x.x), copysignf(e.y, x.y)};
     return (x * 0.5f) * (se + 1.0f);
@@ -358,14 +358,15 @@ __global__ __launch_bounds__(TMT * 128, 2) void gemm_bf16_nt_kernel(GemmArgs g) 
         const int ncol0 = n0 + wn * 64;
         const float bias0 = g.bias[ncol0 + r], bias1 = g.bias[ncol0 + 32 + r];
         if (EPI == EPI_QKV && n0 >= 2 * H) {
-            // V is written TRANSPOSED ([768][T]) for the attention kernel: 4 consecutive tokens per lane already
+            // V goes out in 16-key groups ([Mp/16][768][16]) for the attention kernel's LDS-DMA: a lane holds
+            // 4 consecutive tokens of one feature, i.e. 8 contiguous bytes of that layout.
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                bf16 *dst = g.vt + (size_t)(ncol0 + b * 32 + r - 2 * H) * g.ldvt;
+                const int n = ncol0 + b * 32 + r - 2 * H;
                 const float bias = b ? bias1 : bias0;
 #pragma unroll
                 for (int a = 0; a < TMT; ++a) {
-                    const int mb = m0 + wm * (32 * TMT) + a * 32 + 4 * hh;
+                    const size_t mg = (size_t)(m0 + wm * (32 * TMT) + a * 32) >> 4;   // first 16-token group of the MFMA tile
 #pragma unroll
                     for (int e4 = 0; e4 < 4; ++e4) {
                         bf16x4 o;
@@ -373,7 +374,8 @@ __global__ __launch_bounds__(TMT * 128, 2) void gemm_bf16_nt_kernel(GemmArgs g) 
                         o.y = (bf16)(acc[a][b][e4 * 4 + 1] + bias);
                         o.z = (bf16)(acc[a][b][e4 * 4 + 2] + bias);
                         o.w = (bf16)(acc[a][b][e4 * 4 + 3] + bias);
-                        *reinterpret_cast<bf16x4 *>(dst + mb + 8 * e4) = o;
+                        // tokens 8*e4 + 4*hh + (0..3) of the tile: group e4>>1, slot 8*(e4&1) + 4*hh
+                        *reinterpret_cast<bf16x4 *>(g.v16 + ((mg + (e4 >> 1)) * H + n) * 16 + 8 * (e4 & 1) + 4 * hh) = o;
                     }
                 }
             }
@@ -441,93 +443,121 @@ __global__ __launch_bounds__(TMT * 128, 2) void gemm_bf16_nt_kernel(GemmArgs g) 
     }
 }
 
-// ------------------------------------------------------------------ attention (one wave = 32 query rows of one (seq, head))
+// ------------------------------------------------------------------ attention
 struct AttnArgs {
-    const bf16 *q, *k, *vt;  // q (pre-scaled by 1/8), k: [Mp][768]; vt: [768][ldvt]
-    long ldvt;
-    bf16 *ctx;               // [Mp][768]
+    const bf16 *q, *k;   // q (pre-scaled by 1/8), k: [Mp][768]
+    const bf16 *v16;     // V in 16-key groups: [Mp/16][768][16]  (element (token m, feature n) at ((m>>4)*768 + n)*16 + (m&15))
+    bf16 *ctx;           // [Mp][768]
     SeqInfo s;
-    int cls_only;            // last layer: only the query block holding <s> is needed (models.py:56 takes [:,0])
+    int cls_only;        // last layer: only the query block holding <s> is needed (models.py:56 takes [:,0])
 };
 
-// Workgroup = 4 waves = 256 query rows of one (sequence, head); each wave owns TWO 32-row query blocks,
-// so every K and V^T fragment feeds two MFMAs.  The head's K (len32 x 64 bf16, <= 64 KiB) is staged
-// once per workgroup into LDS by LDS-DMA with the GEMM's XOR swizzle (conflict-free ds_read_b128);
-// V^T fragments come straight from L2 (8-byte loads in the permuted key order of the P operand).
-// Measured before this structure: every wave fetched K twice and V once from L2 per key block and the
-// kernel ran at the L2's ~6 TB/s.
-__global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // K image: row*128 + ((c ^ ((row>>1)&7)) << 4)
+// Workgroup = WAVES waves = ALL query rows of one (sequence, head); a wave owns two 32-row query blocks,
+// so every K and V fragment feeds two MFMAs.  Both the head's K (len32 x 64) and V (64 x len32) live in
+// LDS for the whole workgroup (<= 128 KiB), brought in once by LDS-DMA:
+//   K image   row*128 + ((chunk ^ ((row>>1)&7)) << 4)           (the GEMM's XOR swizzle)
+//   V image   1-KiB pieces (16-key group G, d-tile t): lane l = 32*hh + r holds V[keys 16G+8hh..+7][d = 32t+r],
+//             i.e. a piece IS the A operand of one MFMA and one contiguous KiB of the v16 tensor.
+// Sequences of <= 256 rows take the 4-wave instantiation (<= 64 KiB: two workgroups per CU), longer
+// ones the 8-wave instantiation; both are launched over all sequences and a workgroup whose sequence
+// belongs to the other class leaves at once.
+// History: with V^T fragments fetched per wave from L2 (8-byte loads at a row stride) the kernel ran at
+// the texture-address rate, 0.55 ms per layer at B=256, L=512, and 0.40 ms with those loads removed.
+//
+// Index algebra (v_mfma_f32_32x32x16_bf16; lane = 32*hh + r):
+//   S^T = K.Q^T   A row m <- key 32kb + pi(m), pi = swap bits 2 and 3;  B column n <- query r.
+//                 accumulator e of lane (r, hh)  <->  row m = (e&3) + 8(e>>2) + 4hh.
+//   O^T = V^T.P^T the B operand of k-step s2 is accumulator registers 8*s2 .. 8*s2+7: slot j is row
+//                 m = 16*s2 + 8(j>>2) + 4hh + (j&3), i.e. key pi(m) = 16*s2 + 8hh + j  -- eight consecutive
+//                 keys, which is what a V piece holds.  Output: lane (query r, hh), accumulator e <-> d =
+//                 32t + (e&3) + 8(e>>2) + 4hh: four consecutive features per lane, 1/l is lane-local.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void attention_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.z, head = blockIdx.y;
+    const int b = blockIdx.y, head = blockIdx.x;
     const int len32 = a.s.len32[b];
-    const int qbase = blockIdx.x * 256;
-    if (qbase >= len32) return;  // whole workgroup leaves before any barrier
+    if ((len32 > 256) != (WAVES == 8)) return;  // the other instantiation's sequence (whole workgroup leaves)
     const int len = a.s.lens[b];
     const size_t base = (size_t)a.s.off[b];
     const int r = lane & 31, hh = lane >> 5;
     const int nkb = len32 >> 5;
+    const int q0 = w * 64;
+    const bool active = q0 < len32 && !(a.cls_only && w != 0);
+    unsigned char *vimg = smem + len32 * 128;
 
-    {   // stage K[base .. base+len32)[head*64 .. +64) -> LDS, 8 rows (1 KiB) per wave-instruction
-        typedef const __attribute__((address_space(1))) void *gvp;
-        typedef __attribute__((address_space(3))) void *lvp;
-        // same swizzle as the GEMM image: f(row) = (row >> 1) & 7; rows of this wave's pieces are
-        // r8*8 + (lane>>3) with r8 = w (mod 4), so f = ((w&1)*4 + (lane>>4)) & 7
+    typedef const __attribute__((address_space(1))) void *gvp;
+    typedef __attribute__((address_space(3))) void *lvp;
+    // Q^T fragments (B operand of S^T): lane (q = r, half hh) holds q[16*ks + 8*hh .. +8)
+    bf16x8 qf[2][4];
+    if (active) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const bf16 *qrow = a.q + (base + q0 + u * 32 + r) * H + head * DH + 8 * hh;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) qf[u][ks] = *reinterpret_cast<const bf16x8 *>(qrow + ks * 16);
+        }
+    }
+    {   // K rows -> LDS, 8 rows (1 KiB) per wave-instruction.  Rows of this wave's pieces are r8*8 + (lane>>3)
+        // with r8 = w (mod 2), so the swizzle term is ((w&1)*4 + (lane>>4)) & 7.
         const int srow = lane >> 3, schunk = (lane & 7) ^ ((((w & 1) << 2) + (srow >> 1)) & 7);
         const bf16 *src = a.k + (base + srow) * H + head * DH + schunk * 8;
-        for (int r8 = w; r8 * 8 < len32; r8 += 4)
+        for (int r8 = w; r8 * 8 < len32; r8 += WAVES)
             __builtin_amdgcn_global_load_lds((gvp)(src + (size_t)r8 * 8 * H), (lvp)(smem + r8 * 1024), 16, 0, 0);
     }
-    __syncthreads();  // hipcc drains the LDS-DMA here
-    const int q0 = qbase + w * 64;
-    if (q0 >= len32 || (a.cls_only && w != 0)) return;  // no barriers below
-
-    // Q^T fragments (B operand of S^T = K.Q^T): lane (q = r, half hh) holds q[16*ks + 8*hh .. +8)
-    bf16x8 qf[2][4];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const bf16 *qrow = a.q + (base + q0 + u * 32 + r) * H + head * DH + 8 * hh;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[u][ks] = *reinterpret_cast<const bf16x8 *>(qrow + ks * 16);
+    __syncthreads();  // hipcc drains the LDS-DMA (and the Q loads) here: K is resident
+    {   // V pieces -> LDS while pass 1 runs on K
+        const bf16 *src = a.v16 + ((base >> 4) * H + head * DH) * 16 + r * 16 + hh * 8;
+        for (int p = w; p * 8 < len32; p += WAVES)
+            __builtin_amdgcn_global_load_lds((gvp)(src + ((size_t)(p >> 1) * H + (p & 1) * 32) * 16), (lvp)(vimg + p * 1024), 16, 0, 0);
     }
-    const unsigned char *krow = smem + r * 128;
-    const int sw = (r >> 1) & 7;
+    const int pr = (r & 19) | ((r & 4) << 1) | ((r & 8) >> 1);  // pi(r)
+    const unsigned char *krow = smem + pr * 128;
+    const int sw = (pr >> 1) & 7;
+    const float L2E = 1.44269504088896341f;
+    // key held by accumulator register e of this lane, relative to its key block
+    auto key_of = [&](int e) { return (e & 3) + 4 * ((e >> 2) & 1) + 8 * hh + 16 * (e >> 3); };
 
-    // pass 1: row maxima.  S^T tile: lane column = query r, register e <-> key (e&3) + 8*(e>>2) + 4*hh
-    float mx[2] = {-INFINITY, -INFINITY};
-    for (int kb = 0; kb < nkb; ++kb) {
-        f32x16 s[2];
+    // pass 1: row maxima
+    float mxs[2] = {0.f, 0.f};
+    if (active) {
+        float mx[2] = {-INFINITY, -INFINITY};
+        for (int kb = 0; kb < nkb; ++kb) {
+            f32x16 s[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) s[u][e] = 0.f;
-        const unsigned char *kp = krow + kb * 4096;
+                for (int e = 0; e < 16; ++e) s[u][e] = 0.f;
+            const unsigned char *kp = krow + kb * 4096;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(kp + (((2 * ks + hh) ^ sw) << 4));
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(kp + (((2 * ks + hh) ^ sw) << 4));
 #pragma unroll
-            for (int u = 0; u < 2; ++u) s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[u][ks], s[u], 0, 0, 0);
-        }
-        const int k0 = kb * 32 + 4 * hh;
+                for (int u = 0; u < 2; ++u) s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[u][ks], s[u], 0, 0, 0);
+            }
+            if (kb * 32 + 32 <= len) {   // whole block valid (wave-uniform): no per-key masking
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int key = k0 + (e & 3) + 8 * (e >> 2);
-            if (key < len) {
-                mx[0] = fmaxf(mx[0], s[0][e]);
-                mx[1] = fmaxf(mx[1], s[1][e]);
+                for (int e = 0; e < 16; ++e) {
+                    mx[0] = fmaxf(mx[0], s[0][e]);
+                    mx[1] = fmaxf(mx[1], s[1][e]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (kb * 32 + key_of(e) < len) {
+                        mx[0] = fmaxf(mx[0], s[0][e]);
+                        mx[1] = fmaxf(mx[1], s[1][e]);
+                    }
             }
         }
-    }
-    const float L2E = 1.44269504088896341f;
-    float mxs[2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        mx[u] = fmaxf(mx[u], __shfl_xor(mx[u], 32));
-        mxs[u] = mx[u] * L2E;
+        for (int u = 0; u < 2; ++u) mxs[u] = fmaxf(mx[u], __shfl_xor(mx[u], 32)) * L2E;
     }
+    __syncthreads();  // V is resident (drains this wave's DMA, then meets the others)
+    if (!active) return;
 
-    // pass 2: P = exp(S - max), l = sum P, O = P.V
+    // pass 2: P = exp(S - max), l = sum P, O^T = V^T.P^T
     float lsum[2] = {0.f, 0.f};
     f32x16 o[2][2];
 #pragma unroll
@@ -536,19 +566,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int e = 0; e < 16; ++e) o[u][t][e] = 0.f;
-    const bf16 *vbase = a.vt + (size_t)(head * DH + r) * a.ldvt + base + 4 * hh;
-    for (int kb = 0; kb < nkb; ++kb) {
-        // V^T fragments first: their L2 latency hides under the S^T MFMAs and the exponentials
-        bf16x4 v0[2][2], v1[2][2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const bf16 *vp = vbase + (size_t)(t * 32) * a.ldvt + kb * 32;
-#pragma unroll
-            for (int sidx = 0; sidx < 2; ++sidx) {
-                v0[t][sidx] = *reinterpret_cast<const bf16x4 *>(vp + 16 * sidx);
-                v1[t][sidx] = *reinterpret_cast<const bf16x4 *>(vp + 16 * sidx + 8);
-            }
-        }
+    const unsigned char *vlane = vimg + lane * 16;
+    auto step = [&](int kb, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
         f32x16 s[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u)
@@ -561,46 +581,49 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs a) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[u][ks], s[u], 0, 0, 0);
         }
-        const int k0 = kb * 32 + 4 * hh;
+        // exponentials: raw v_exp_f32 (arguments are <= 0, results in (0,1]; libm's exp2f wraps every
+        // call in range checks and ldexp: 5 VALU instead of 1)
         bf16x8 pf[2][2];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int key = k0 + (e & 3) + 8 * (e >> 2);
-            const bool valid = key < len;
+            const bool valid = !MASKED || kb * 32 + key_of(e) < len;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const float p = valid ? exp2f(s[u][e] * L2E - mxs[u]) : 0.f;
+                const float p = valid ? __builtin_amdgcn_exp2f(fmaf(s[u][e], L2E, -mxs[u])) : 0.f;
                 lsum[u] += p;
                 pf[u][e >> 3][e & 7] = (bf16)p;
             }
         }
-        // P (registers 8s..8s+7 of the S^T accumulator) is the A operand of k-step s; slot j of half hh is
-        // key 16s + 8(j>>2) + 4hh + (j&3): V^T fragments were fetched in exactly that key order.
+        const unsigned char *vp = vlane + kb * 4096;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-            for (int sidx = 0; sidx < 2; ++sidx) {
-                bf16x8 vf;
-                vf[0] = v0[t][sidx].x; vf[1] = v0[t][sidx].y; vf[2] = v0[t][sidx].z; vf[3] = v0[t][sidx].w;
-                vf[4] = v1[t][sidx].x; vf[5] = v1[t][sidx].y; vf[6] = v1[t][sidx].z; vf[7] = v1[t][sidx].w;
+            for (int t = 0; t < 2; ++t) {
+                const bf16x8 vf = *reinterpret_cast<const bf16x8 *>(vp + (s2 * 2 + t) * 1024);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) o[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[u][sidx], vf, o[u][t], 0, 0, 0);
+                for (int u = 0; u < 2; ++u) o[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[u][s2], o[u][t], 0, 0, 0);
             }
-    }
+    };
+    const int nfull = len >> 5;  // key blocks without padding keys (nkb - nfull is 0 or 1)
+    for (int kb = 0; kb < nfull; ++kb) step(kb, std::false_type{});
+    if (nfull < nkb) step(nfull, std::true_type{});
+
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         if (q0 + u * 32 >= len32 || (a.cls_only && u)) break;  // past the sequence (computed on foreign rows) or not needed
-        const float l = lsum[u] + __shfl_xor(lsum[u], 32);
-        const float inv = 1.0f / l;  // lane r holds 1/l of query r (both halves)
-        // O tile t: lane column = d = 32t + r, register e <-> query row (e&3) + 8*(e>>2) + 4*hh
-        bf16 *crow = a.ctx + (base + q0 + u * 32) * H + head * DH + r;
+        const float inv = 1.0f / (lsum[u] + __shfl_xor(lsum[u], 32));
+        bf16 *crow = a.ctx + (base + q0 + u * 32 + r) * H + head * DH + 4 * hh;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int qr = (e & 3) + 8 * (e >> 2) + 4 * hh;
-            const float sc = __shfl(inv, qr);
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) crow[(size_t)qr * H + 32 * t] = (bf16)(o[u][t][e] * sc);
-        }
+            for (int g4 = 0; g4 < 4; ++g4) {
+                bf16x4 ov;
+                ov.x = (bf16)(o[u][t][g4 * 4 + 0] * inv);
+                ov.y = (bf16)(o[u][t][g4 * 4 + 1] * inv);
+                ov.z = (bf16)(o[u][t][g4 * 4 + 2] * inv);
+                ov.w = (bf16)(o[u][t][g4 * 4 + 3] * inv);
+                *reinterpret_cast<bf16x4 *>(crow + 32 * t + 8 * g4) = ov;
+            }
     }
 }
 
@@ -744,7 +767,7 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
     HAC_TRY(e->ws_xb.reserve((size_t)Mp * H * 2));
     HAC_TRY(e->ws_q.reserve((size_t)Mp * H * 2));
     HAC_TRY(e->ws_k.reserve((size_t)(Mp + 64) * H * 2));
-    HAC_TRY(e->ws_vt.reserve((size_t)H * (Mp + 64) * 2));
+    HAC_TRY(e->ws_vt.reserve((size_t)H * Mp * 2));
     HAC_TRY(e->ws_ctx.reserve((size_t)Mp * H * 2));
     HAC_TRY(e->ws_h.reserve((size_t)Mp * FF * 2));
     const size_t seq_ints = (size_t)3 * B + 2 + 2 + (size_t)B * L;
@@ -763,7 +786,6 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
     float *x = (float *)e->ws_x.p, *y = (float *)e->ws_y.p;
     bf16 *xb = (bf16 *)e->ws_xb.p, *q = (bf16 *)e->ws_q.p, *k = (bf16 *)e->ws_k.p, *vt = (bf16 *)e->ws_vt.p;
     bf16 *ctx = (bf16 *)e->ws_ctx.p, *h = (bf16 *)e->ws_h.p;
-    const long ldvt = Mp + 64;
     // dead tail rows of the last M tile feed the GEMMs: keep them finite
     HAC_HIP(hipMemsetAsync(xb, 0, (size_t)Mp * H * 2, st));
     HAC_HIP(hipMemsetAsync(x, 0, (size_t)Mp * H * 4, st));
@@ -805,10 +827,12 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
         GemmArgs g{};
         g.total_rows = total;
         // QKV
-        g.A = xb; g.W = w.wqkv; g.bias = w.bqkv; g.N = 3 * H; g.K = H; g.q = q; g.k = k; g.vt = vt; g.ldvt = ldvt;
+        g.A = xb; g.W = w.wqkv; g.bias = w.bqkv; g.N = 3 * H; g.K = H; g.q = q; g.k = k; g.v16 = vt;
         HAC_GEMM(EPI_QKV, 3 * H);
-        AttnArgs a{q, k, vt, ldvt, ctx, s, last ? 1 : 0};
-        attention_kernel<<<dim3(last ? 1 : (L32 + 255) / 256, NH, B), dim3(256), (size_t)L32 * 128, st>>>(a);
+        AttnArgs a{q, k, vt, ctx, s, last ? 1 : 0};
+        // sequences of <= 256 rows: 4-wave workgroups; longer ones: 8-wave workgroups (each skips the other's)
+        attention_kernel<4><<<dim3(NH, B), dim3(256), (size_t)(L32 < 256 ? L32 : 256) * 256, st>>>(a);
+        if (L32 > 256) attention_kernel<8><<<dim3(NH, B), dim3(512), (size_t)L32 * 256, st>>>(a);
         if (!last) {
             // attention output projection + residual, LN
             g.A = ctx; g.W = w.wo; g.bias = w.bo; g.N = H; g.K = H; g.resid = x; g.y = y;
@@ -882,7 +906,8 @@ int hac_encoder_create(const hac_encoder_config *cfg, int device, hac_encoder **
         delete e;
         return fail(HAC_ERR_HIP, "hipStreamCreate failed");
     }
-    (void)hipFuncSetAttribute((const void *)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void *)attention_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void *)attention_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_QKV, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
     (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_RESID, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
     (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_GELU, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
