@@ -425,8 +425,8 @@ __global__ __launch_bounds__(TMT * 128, 2) void gemm_bf16_nt_kernel(GemmArgs g) 
                             o[0] = (bf16)g0.x; o[1] = (bf16)g0.y; o[2] = (bf16)g1.x; o[3] = (bf16)g1.y;
                             o[4] = (bf16)g2.x; o[5] = (bf16)g2.y; o[6] = (bf16)g3.x; o[7] = (bf16)g3.y;
                             *reinterpret_cast<bf16x8 *>(g.h + (mrow + row) * (size_t)g.N + ncol0 + c8) = o;
-                        } else {  // Q (scaled by 1/sqrt(64): exact, a power of two) or K
-                            const float sc = n0 < H ? 0.125f : 1.0f;
+                        } else {  // Q (scaled by log2(e)/sqrt(64) in fp32, before the one rounding to bf16: the softmax runs in base 2) or K
+                            const float sc = n0 < H ? 0.125f * 1.44269504088896341f : 1.0f;
                             o[0] = (bf16)(v0.x * sc); o[1] = (bf16)(v0.y * sc); o[2] = (bf16)(v0.z * sc); o[3] = (bf16)(v0.w * sc);
                             o[4] = (bf16)(v1.x * sc); o[5] = (bf16)(v1.y * sc); o[6] = (bf16)(v1.z * sc); o[7] = (bf16)(v1.w * sc);
                             bf16 *dst = n0 < H ? g.q : g.k;
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(TMT * 128, 2) void gemm_bf16_nt_kernel(GemmArgs g) 
 
 // ------------------------------------------------------------------ attention
 struct AttnArgs {
-    const bf16 *q, *k;   // q (pre-scaled by 1/8), k: [Mp][768]
+    const bf16 *q, *k;   // q (pre-scaled by log2(e)/8), k: [Mp][768]
     const bf16 *v16;     // V in 16-key groups: [Mp/16][768][16]  (element (token m, feature n) at ((m>>4)*768 + n)*16 + (m&15))
     bf16 *ctx;           // [Mp][768]
     SeqInfo s;
@@ -515,7 +515,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void attention_kern
     const int pr = (r & 19) | ((r & 4) << 1) | ((r & 8) >> 1);  // pi(r)
     const unsigned char *krow = smem + pr * 128;
     const int sw = (pr >> 1) & 7;
-    const float L2E = 1.44269504088896341f;
     // key held by accumulator register e of this lane, relative to its key block
     auto key_of = [&](int e) { return (e & 3) + 4 * ((e >> 2) & 1) + 8 * hh + 16 * (e >> 3); };
 
@@ -552,7 +551,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void attention_kern
             }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) mxs[u] = fmaxf(mx[u], __shfl_xor(mx[u], 32)) * L2E;
+        for (int u = 0; u < 2; ++u) mxs[u] = fmaxf(mx[u], __shfl_xor(mx[u], 32));
     }
     __syncthreads();  // V is resident (drains this wave's DMA, then meets the others)
     if (!active) return;
@@ -567,42 +566,51 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void attention_kern
 #pragma unroll
             for (int e = 0; e < 16; ++e) o[u][t][e] = 0.f;
     const unsigned char *vlane = vimg + lane * 16;
+    // The scores are already in the log2 domain (Q carries log2(e)/8) and the S^T accumulator starts at
+    // -max, so P = 2^acc with no VALU between the MFMA and the v_exp.  K fragments are read one key
+    // block ahead (two waves per SIMD do not hide an LDS round trip in front of every MFMA pair).
+    bf16x8 kc[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kc[ks] = *reinterpret_cast<const bf16x8 *>(krow + (((2 * ks + hh) ^ sw) << 4));
     auto step = [&](int kb, auto masked_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         f32x16 s[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) s[u][e] = 0.f;
-        const unsigned char *kp = krow + kb * 4096;
+            for (int e = 0; e < 16; ++e) s[u][e] = -mxs[u];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(kp + (((2 * ks + hh) ^ sw) << 4));
+        for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[u][ks], s[u], 0, 0, 0);
-        }
-        // exponentials: raw v_exp_f32 (arguments are <= 0, results in (0,1]; libm's exp2f wraps every
-        // call in range checks and ldexp: 5 VALU instead of 1)
+            for (int u = 0; u < 2; ++u) s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc[ks], qf[u][ks], s[u], 0, 0, 0);
+        const unsigned char *vp = vlane + kb * 4096;
+        bf16x8 vf[2][2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) vf[s2][t] = *reinterpret_cast<const bf16x8 *>(vp + (s2 * 2 + t) * 1024);
+        const unsigned char *kp = krow + min(kb + 1, nkb - 1) * 4096;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) kc[ks] = *reinterpret_cast<const bf16x8 *>(kp + (((2 * ks + hh) ^ sw) << 4));
+        // raw v_exp_f32: arguments are <= 0 (up to rounding), results in (0,1]; libm's exp2f wraps every
+        // call in range checks and ldexp, 5 VALU instead of 1
         bf16x8 pf[2][2];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const bool valid = !MASKED || kb * 32 + key_of(e) < len;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const float p = valid ? __builtin_amdgcn_exp2f(fmaf(s[u][e], L2E, -mxs[u])) : 0.f;
+                const float p = valid ? __builtin_amdgcn_exp2f(s[u][e]) : 0.f;
                 lsum[u] += p;
                 pf[u][e >> 3][e & 7] = (bf16)p;
             }
         }
-        const unsigned char *vp = vlane + kb * 4096;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const bf16x8 vf = *reinterpret_cast<const bf16x8 *>(vp + (s2 * 2 + t) * 1024);
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int u = 0; u < 2; ++u) o[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[u][s2], o[u][t], 0, 0, 0);
-            }
+                for (int u = 0; u < 2; ++u) o[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s2][t], pf[u][s2], o[u][t], 0, 0, 0);
     };
     const int nfull = len >> 5;  // key blocks without padding keys (nkb - nfull is 0 or 1)
     for (int kb = 0; kb < nfull; ++kb) step(kb, std::false_type{});
