@@ -773,6 +773,8 @@ u32 next_pow2(u32 v) {
     return p;
 }
 
+#include "scan_split.inc"
+
 // ------------------------------------------------------------------ one-device index
 struct Segment {
     float4 *buf = nullptr;
@@ -788,6 +790,11 @@ struct DeviceIndex {
     SegDesc *d_segs = nullptr;
     bool segs_dirty = true;
     GrowBuf ws_partial, ws_pcnt, ws_seedkeys, ws_thr, ws_thrglob, ws_q, ws_qt, ws_keys, ws_D, ws_I, ws_stage[2];
+    // split-bf16 prefilter path (scan_split.inc)
+    GrowBuf ws_norm, ws_qsplit, ws_delta, ws_cand, ws_akeys, ws_fail, ws_stat, ws_fbidx, ws_fbq, ws_fbkeys;
+    u32 *h_fb = nullptr;       // pinned: [0] failed queries, [1] max |s~ - s| / delta (float bits), [2..] flags / indices
+    size_t h_fb_words = 0;
+    long split_searches = 0, split_fallback_queries = 0;
     void *h_stage[2] = {nullptr, nullptr};
     size_t h_stage_bytes = 0;
     // Small host<->device traffic (queries, results, segment table) always goes through
@@ -824,6 +831,8 @@ struct DeviceIndex {
         HAC_HIP(hipMalloc((void **)&d_segs, sizeof(SegDesc) * MAX_SEG));
         HAC_HIP(hipHostMalloc((void **)&h_segs, sizeof(SegDesc) * MAX_SEG, hipHostMallocDefault));
         for (int i = 0; i < 2; ++i) HAC_HIP(hipEventCreateWithFlags(&stage_ev[i], hipEventDisableTiming));
+        HAC_TRY(ws_norm.reserve(16));
+        HAC_HIP(hipMemsetAsync(ws_norm.p, 0, 16, stream));
         static bool attr_done[64] = {false};
         if (device < 64 && !attr_done[device]) {
             HAC_HIP(hipFuncSetAttribute((const void *)scan16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -835,6 +844,7 @@ struct DeviceIndex {
                                 (const void *)scanq_kernel<3, 8>, (const void *)scanq_kernel<4, 8>};
             for (const void *f : fq) HAC_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
             HAC_HIP(hipFuncSetAttribute((const void *)sample_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * 1024)));
+            HAC_HIP(hipFuncSetAttribute((const void *)scanb_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
             attr_done[device] = true;
         }
         return HAC_OK;
@@ -850,8 +860,10 @@ struct DeviceIndex {
         if (h_segs) (void)hipHostFree(h_segs);
         if (h_pin) (void)hipHostFree(h_pin);
         for (GrowBuf *b : {&ws_partial, &ws_pcnt, &ws_seedkeys, &ws_thr, &ws_thrglob, &ws_q, &ws_qt, &ws_keys, &ws_D, &ws_I, &ws_stage[0],
-                           &ws_stage[1]})
+                           &ws_stage[1], &ws_norm, &ws_qsplit, &ws_delta, &ws_cand, &ws_akeys, &ws_fail, &ws_stat, &ws_fbidx, &ws_fbq,
+                           &ws_fbkeys})
             b->release();
+        if (h_fb) (void)hipHostFree(h_fb);
         for (int i = 0; i < 2; ++i) {
             if (h_stage[i]) (void)hipHostFree(h_stage[i]);
             if (stage_ev[i]) (void)hipEventDestroy(stage_ev[i]);
@@ -883,6 +895,8 @@ struct DeviceIndex {
         segs.swap(keep);
         ntotal = 0;
         segs_dirty = true;
+        HAC_HIP(hipMemsetAsync(ws_norm.p, 0, 16, stream));
+        HAC_HIP(hipStreamSynchronize(stream));
         return HAC_OK;
     }
 
@@ -940,6 +954,10 @@ struct DeviceIndex {
             const long g_lo = row0 / GROUP_ROWS, g_hi = (row0 + m + GROUP_ROWS - 1) / GROUP_ROWS;
             tile_rows_kernel<<<dim3((unsigned)(g_hi - g_lo)), dim3(256), 0, st>>>(
                 reinterpret_cast<const float4 *>(src_dev + (size_t)done * d), (long)m, K4, s.buf, row0);
+            HAC_HIP(hipGetLastError());
+            // largest row norm of the index (error bound of the split-bf16 prefilter)
+            row_norm_max_kernel<<<dim3((unsigned)((g_hi - g_lo + 3) / 4)), dim3(256), 0, st>>>(s.buf, K4, row0, row0 + (long)m,
+                                                                                             (u32 *)ws_norm.p);
             HAC_HIP(hipGetLastError());
             s.rows += m;
             done += m;
@@ -1140,8 +1158,8 @@ struct DeviceIndex {
         return HAC_OK;
     }
 
-    // keys_out: device u64 [nq][k]
-    int search_keys(const float *q_dev, int64_t nq, int k, u64 *keys_out, u32 pos_base, hipStream_t st) {
+    // keys_out: device u64 [nq][k]; the exact fp32 kernels only
+    int search_keys_exact(const float *q_dev, int64_t nq, int k, u64 *keys_out, u32 pos_base, hipStream_t st) {
         if (nq == 0) return HAC_OK;
         if (((uintptr_t)q_dev & 15) != 0) return fail(HAC_ERR_INVALID, "search: query pointer must be 16-byte aligned");
         if ((uint64_t)pos_base + (uint64_t)ntotal > 0xFFFFFFFFull) return fail(HAC_ERR_UNSUPPORTED, "row positions exceed 32 bits");
@@ -1200,6 +1218,198 @@ struct DeviceIndex {
         HAC_TRY(run_merge(pl, (const u64 *)ws_partial.p, pl.P, (size_t)k, (size_t)pl.P * k, nq, k, keys_out, nullptr, st,
                           (const u32 *)ws_pcnt.p));
         return HAC_OK;
+    }
+
+    // ---- split-bf16 prefilter + exact rescoring (scan_split.inc): same results, ~3x the query rate when the
+    // exact kernels are bound by the fp32 matrix rate.  Worth its fixed cost only for many (query, row) pairs.
+    static constexpr int SPLIT_K2 = 256, SPLIT_C2 = 512;
+    bool split_eligible(int64_t nq, int k) const {
+        const char *e = getenv("HAC_SPLIT");   // "0": never, "1": whenever supported (tests), unset: by size
+        if (e && e[0] == '0') return false;
+        if (K4 % 16 != 0 || d > HAC_MAX_D || k > SPLIT_K2 - 64 || ntotal < SPLIT_K2) return false;
+        if (e && e[0] == '1') return true;
+        return nq >= 48 && (double)nq * (double)ntotal >= 1.0e8;
+    }
+
+    int fb_reserve(size_t words) {
+        if (words <= h_fb_words) return HAC_OK;
+        if (h_fb) (void)hipHostFree(h_fb);
+        h_fb = nullptr;
+        h_fb_words = 0;
+        hipError_t e = hipHostMalloc((void **)&h_fb, words * 4 * 2, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(HAC_ERR_OOM, "hipHostMalloc(%zu) failed: %s", words * 8, hipGetErrorString(e));
+        h_fb_words = words * 2;
+        return HAC_OK;
+    }
+
+    int search_keys_split(const float *q_dev, int64_t nq, int k, u64 *keys_out, u32 pos_base, hipStream_t st) {
+        const int K2 = SPLIT_K2, C2 = SPLIT_C2;
+        HAC_TRY(upload_segs(st));
+        const u32 G = (u32)((ntotal + GROUP_ROWS - 1) / GROUP_ROWS);
+        const int n_qtiles = (int)((nq + SB_NQ - 1) / SB_NQ);
+        const int64_t nq_pad = (int64_t)n_qtiles * SB_NQ;
+        long P = std::max<long>(1, n_cu / n_qtiles);
+        if (P >= 8) P = P / 8 * 8;  // same-row workgroups of different query tiles share an XCD (L2)
+        P = std::max<long>(1, std::min<long>(P, (G + SB_W - 1) / SB_W));
+        const size_t lds = (size_t)2 * SB_SLICE * 16 + (size_t)SB_W * C2 * 8 + (size_t)SB_NQ * 8 + 16;
+        HAC_TRY(ws_qsplit.reserve((size_t)nq_pad * d * 4));
+        HAC_TRY(ws_delta.reserve((size_t)nq_pad * 4));
+        HAC_TRY(ws_cand.reserve((size_t)P * n_qtiles * SB_NQ * C2 * 8));
+        const long pstride = (long)(P + 1) * K2;
+        HAC_TRY(ws_partial.reserve((size_t)nq * pstride * 8));
+        HAC_TRY(ws_pcnt.reserve((size_t)nq * 4));
+        HAC_TRY(ws_thrglob.reserve((size_t)nq_pad * 4));
+        HAC_TRY(ws_akeys.reserve((size_t)nq * K2 * 8));
+        HAC_TRY(ws_fail.reserve((size_t)nq * 4));
+        HAC_TRY(ws_stat.reserve(16));
+        HAC_TRY(ws_thr.reserve((size_t)nq * 8));
+        HAC_TRY(fb_reserve((size_t)nq + 8));
+
+        split_queries_kernel<<<dim3((unsigned)nq_pad), dim3(192), 0, st>>>(reinterpret_cast<const float4 *>(q_dev), (int)nq, K4,
+                                                                          (const u32 *)ws_norm.p, (bf16 *)ws_qsplit.p,
+                                                                          (float *)ws_delta.p);
+        HAC_HIP(hipGetLastError());
+
+        ScanArgs a{};
+        a.segs = d_segs;
+        a.nseg = nseg_live;
+        a.q = reinterpret_cast<const float4 *>(q_dev);
+        a.nq = (int)nq;
+        a.K4 = K4;
+        a.n_rows = (long)ntotal;
+        a.pos_base = pos_base;
+        // seed: a lower bound of every query's K2-th canonical score (exact fp32 sample, as in the exact path)
+        float *thr_a = (float *)ws_thr.p, *thr_b = thr_a + nq;
+        const float *thr_init = nullptr;
+        const u32 n_sample = std::max<u32>(std::max<u32>(64u, G / 128u), ((u32)K2 + 1u) / 2u);
+        if (G >= 4u * n_sample) {
+            const u32 S = 4u * n_sample;
+            HAC_TRY(ws_seedkeys.reserve((size_t)nq * S * 4));
+            ScanArgs sa = a;
+            sa.g_first = 0;
+            sa.g_step = G / n_sample;
+            sa.n_items = n_sample;
+            const int qt16 = (int)((nq + 15) / 16);
+            sample_scores_kernel<<<dim3((n_sample + SCAN_WAVES - 1) / SCAN_WAVES, (unsigned)qt16), dim3(SCAN_WAVES * 64),
+                                   (size_t)K4 * 16 * 16, st>>>(sa, (float *)ws_seedkeys.p, S);
+            HAC_HIP(hipGetLastError());
+            kth_select_kernel<<<dim3((unsigned)nq), dim3(256), 0, st>>>((const float *)ws_seedkeys.p, S, K2, thr_a);
+            HAC_HIP(hipGetLastError());
+            thr_init = thr_a;
+        }
+        a.k = K2;
+        a.g_step = 1;
+        a.thr_glob = (u32 *)ws_thrglob.p;
+        a.partial = (u64 *)ws_partial.p;
+        a.partial_cnt = (u32 *)ws_pcnt.p;
+        SplitArgs sp{};
+        sp.qsplit = (const u32x4 *)ws_qsplit.p;
+        sp.delta = (const float *)ws_delta.p;
+        sp.cand = (u64 *)ws_cand.p;
+        sp.C2 = C2;
+        sp.K2 = K2;
+        sp.pstride = pstride;
+        HAC_HIP(hipMemsetAsync(ws_pcnt.p, 0, (size_t)nq * 4, st));
+        HAC_HIP(hipMemsetAsync(ws_thrglob.p, 0, (size_t)nq_pad * 4, st));
+        HAC_HIP(hipMemsetAsync(ws_stat.p, 0, 16, st));
+        Plan plm{};
+        plm.Cm = (int)next_pow2((u32)K2 + MERGE_THREADS);
+        plm.lds_merge = (size_t)plm.Cm * 8 + 32;
+        if (profiling) {
+            if (ev_used == ev_pool.size()) {
+                hipEvent_t a0, a1;
+                HAC_HIP(hipEventCreate(&a0));
+                HAC_HIP(hipEventCreate(&a1));
+                ev_pool.emplace_back(a0, a1);
+            }
+            HAC_HIP(hipEventRecord(ev_pool[ev_used].first, st));
+        }
+        // Two phases.  The first eighth of the corpus runs on the sample's (loose) thresholds; its merged K2-th
+        // scores then bound the rest sharply enough (K2 rows out of N/8 pass) that candidate lists hardly
+        // ever fill: with the loose thresholds alone, list compactions cost as much as half the MFMA work.
+        const u32 round_groups = (u32)P * SB_W;
+        u32 GA = (G / 8u + round_groups - 1u) / round_groups * round_groups;
+        if (GA * 2u > G) GA = 0;   // small index: one phase
+        if (GA) {
+            a.g_first = 0;
+            a.n_items = GA;
+            a.thr_init = thr_init;
+            sp.thr_is_approx = 0;
+            scanb_kernel<<<dim3((unsigned)P, (unsigned)n_qtiles), dim3(SB_W * 64), lds, st>>>(a, sp);
+            HAC_HIP(hipGetLastError());
+            HAC_TRY(run_merge(plm, (const u64 *)ws_partial.p, (int)P, (size_t)K2, (size_t)pstride, nq, K2, (u64 *)ws_akeys.p, thr_b, st,
+                              (const u32 *)ws_pcnt.p));
+            seed_lists_kernel<<<dim3((unsigned)((nq * K2 + 255) / 256)), dim3(256), 0, st>>>((const u64 *)ws_akeys.p, K2, pstride, (long)nq,
+                                                                                             (u64 *)ws_partial.p, (u32 *)ws_pcnt.p);
+            HAC_HIP(hipGetLastError());
+        }
+        a.g_first = GA;
+        a.n_items = G - GA;
+        a.thr_init = GA ? thr_b : thr_init;
+        sp.thr_is_approx = GA ? 1 : 0;
+        scanb_kernel<<<dim3((unsigned)P, (unsigned)n_qtiles), dim3(SB_W * 64), lds, st>>>(a, sp);
+        HAC_HIP(hipGetLastError());
+        if (profiling) {
+            HAC_HIP(hipEventRecord(ev_pool[ev_used].second, st));
+            ++ev_used;
+        }
+        // exact top-K2 by approximate score over all workgroups' survivors
+        HAC_TRY(run_merge(plm, (const u64 *)ws_partial.p, (int)P + 1, (size_t)K2, (size_t)pstride, nq, K2, (u64 *)ws_akeys.p, nullptr, st,
+                          (const u32 *)ws_pcnt.p));
+        rescore_kernel<<<dim3((unsigned)nq), dim3(256), 0, st>>>(a, (const u64 *)ws_akeys.p, (const float *)ws_delta.p, K2, k, keys_out,
+                                                               (u32 *)ws_fail.p, (u32 *)ws_stat.p);
+        HAC_HIP(hipGetLastError());
+        HAC_HIP(hipMemcpyAsync(h_fb, ws_stat.p, 8, hipMemcpyDeviceToHost, st));
+        HAC_HIP(hipStreamSynchronize(st));
+        const u32 nfail = h_fb[0];
+        float maxratio;
+        std::memcpy(&maxratio, &h_fb[1], 4);
+        ++split_searches;
+        split_fallback_queries += nfail;
+        snprintf(last_plan, sizeof last_plan, "split: scanb_kernel grid=(%ld,%d) NQ=%d K2=%d lds=%zu seed=%d fallback=%u/%lld err/bound=%.3g",
+                 P, n_qtiles, SB_NQ, K2, lds, thr_init ? 1 : 0, nfail, (long long)nq, (double)maxratio);
+        if (nfail == 0) return HAC_OK;
+
+        // certificate failed for some queries: the exact kernels decide those
+        HAC_HIP(hipMemcpyAsync(h_fb + 8, ws_fail.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+        HAC_HIP(hipStreamSynchronize(st));
+        std::vector<int> idx;
+        idx.reserve(nfail);
+        for (int64_t i = 0; i < nq; ++i)
+            if (h_fb[8 + i]) idx.push_back((int)i);
+        const int nf = (int)idx.size();
+        std::memcpy(h_fb + 8, idx.data(), (size_t)nf * 4);
+        HAC_TRY(ws_fbidx.reserve((size_t)nf * 4));
+        HAC_TRY(ws_fbq.reserve((size_t)nf * d * 4));
+        HAC_TRY(ws_fbkeys.reserve((size_t)nf * k * 8));
+        HAC_HIP(hipMemcpyAsync(ws_fbidx.p, h_fb + 8, (size_t)nf * 4, hipMemcpyHostToDevice, st));
+        gather_rows_kernel<<<dim3((unsigned)(((long)nf * K4 + 255) / 256)), dim3(256), 0, st>>>(
+            reinterpret_cast<const float4 *>(q_dev), (const int *)ws_fbidx.p, nf, K4, (float4 *)ws_fbq.p);
+        HAC_HIP(hipGetLastError());
+        char keep_plan[sizeof last_plan];
+        std::memcpy(keep_plan, last_plan, sizeof last_plan);
+        const bool prof = profiling;
+        profiling = false;   // one timed kernel per search: the prefilter
+        const int rc = search_keys_exact((const float *)ws_fbq.p, nf, k, (u64 *)ws_fbkeys.p, pos_base, st);
+        profiling = prof;
+        std::memcpy(last_plan, keep_plan, sizeof last_plan);
+        HAC_TRY(rc);
+        scatter_keys_kernel<<<dim3((unsigned)(((long)nf * k + 255) / 256)), dim3(256), 0, st>>>((const u64 *)ws_fbkeys.p,
+                                                                                              (const int *)ws_fbidx.p, nf, k, keys_out);
+        HAC_HIP(hipGetLastError());
+        // h_fb is reused by the next search: the index upload above must have been consumed
+        HAC_HIP(hipStreamSynchronize(st));
+        return HAC_OK;
+    }
+
+    // keys_out: device u64 [nq][k], canonical (score desc, row asc) keys of the k best rows per query
+    int search_keys(const float *q_dev, int64_t nq, int k, u64 *keys_out, u32 pos_base, hipStream_t st) {
+        if (nq > 0 && ntotal > 0 && split_eligible(nq, k)) {
+            if (((uintptr_t)q_dev & 15) != 0) return fail(HAC_ERR_INVALID, "search: query pointer must be 16-byte aligned");
+            if ((uint64_t)pos_base + (uint64_t)ntotal > 0xFFFFFFFFull) return fail(HAC_ERR_UNSUPPORTED, "row positions exceed 32 bits");
+            return search_keys_split(q_dev, nq, k, keys_out, pos_base, st);
+        }
+        return search_keys_exact(q_dev, nq, k, keys_out, pos_base, st);
     }
 };
 
