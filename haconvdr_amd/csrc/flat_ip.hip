@@ -25,6 +25,7 @@
 #include "hac_common.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
@@ -1251,7 +1252,7 @@ struct DeviceIndex {
         long P = std::max<long>(1, n_cu / n_qtiles);
         if (P >= 8) P = P / 8 * 8;  // same-row workgroups of different query tiles share an XCD (L2)
         P = std::max<long>(1, std::min<long>(P, (G + SB_W - 1) / SB_W));
-        const size_t lds = (size_t)2 * SB_SLICE * 16 + (size_t)SB_W * C2 * 8 + (size_t)SB_NQ * 8 + 16;
+        const size_t lds = scanb_lds_bytes();
         HAC_TRY(ws_qsplit.reserve((size_t)nq_pad * d * 4));
         HAC_TRY(ws_delta.reserve((size_t)nq_pad * 4));
         HAC_TRY(ws_cand.reserve((size_t)P * n_qtiles * SB_NQ * C2 * 8));
@@ -1312,9 +1313,6 @@ struct DeviceIndex {
         HAC_HIP(hipMemsetAsync(ws_pcnt.p, 0, (size_t)nq * 4, st));
         HAC_HIP(hipMemsetAsync(ws_thrglob.p, 0, (size_t)nq_pad * 4, st));
         HAC_HIP(hipMemsetAsync(ws_stat.p, 0, 16, st));
-        Plan plm{};
-        plm.Cm = (int)next_pow2((u32)K2 + MERGE_THREADS);
-        plm.lds_merge = (size_t)plm.Cm * 8 + 32;
         if (profiling) {
             if (ev_used == ev_pool.size()) {
                 hipEvent_t a0, a1;
@@ -1324,11 +1322,12 @@ struct DeviceIndex {
             }
             HAC_HIP(hipEventRecord(ev_pool[ev_used].first, st));
         }
-        // Two phases.  The first eighth of the corpus runs on the sample's (loose) thresholds; its merged K2-th
-        // scores then bound the rest sharply enough (K2 rows out of N/8 pass) that candidate lists hardly
+        // Two phases.  The first sixteenth of the corpus runs on the sample's (loose) thresholds; its merged K2-th
+        // scores then bound the rest sharply enough (K2 rows out of N/16 pass) that candidate lists hardly
         // ever fill: with the loose thresholds alone, list compactions cost as much as half the MFMA work.
         const u32 round_groups = (u32)P * SB_W;
-        u32 GA = (G / 8u + round_groups - 1u) / round_groups * round_groups;
+        // at least ~48k rows (K2 of them = 0.5 % pass the second phase's thresholds), a sixteenth of a large index
+        u32 GA = (std::max<u32>(G / 16u, 768u) + round_groups - 1u) / round_groups * round_groups;
         if (GA * 2u > G) GA = 0;   // small index: one phase
         if (GA) {
             a.g_first = 0;
@@ -1337,8 +1336,10 @@ struct DeviceIndex {
             sp.thr_is_approx = 0;
             scanb_kernel<<<dim3((unsigned)P, (unsigned)n_qtiles), dim3(SB_W * 64), lds, st>>>(a, sp);
             HAC_HIP(hipGetLastError());
-            HAC_TRY(run_merge(plm, (const u64 *)ws_partial.p, (int)P, (size_t)K2, (size_t)pstride, nq, K2, (u64 *)ws_akeys.p, thr_b, st,
-                              (const u32 *)ws_pcnt.p));
+            select_keys_kernel<<<dim3((unsigned)nq), dim3(256), (size_t)K2 * 8, st>>>((const u64 *)ws_partial.p, (size_t)pstride,
+                                                                                      (const u32 *)ws_pcnt.p, (u32)pstride, K2, K2,
+                                                                                      (u64 *)ws_akeys.p, thr_b);
+            HAC_HIP(hipGetLastError());
             seed_lists_kernel<<<dim3((unsigned)((nq * K2 + 255) / 256)), dim3(256), 0, st>>>((const u64 *)ws_akeys.p, K2, pstride, (long)nq,
                                                                                              (u64 *)ws_partial.p, (u32 *)ws_pcnt.p);
             HAC_HIP(hipGetLastError());
@@ -1354,8 +1355,10 @@ struct DeviceIndex {
             ++ev_used;
         }
         // exact top-K2 by approximate score over all workgroups' survivors
-        HAC_TRY(run_merge(plm, (const u64 *)ws_partial.p, (int)P + 1, (size_t)K2, (size_t)pstride, nq, K2, (u64 *)ws_akeys.p, nullptr, st,
-                          (const u32 *)ws_pcnt.p));
+        select_keys_kernel<<<dim3((unsigned)nq), dim3(256), (size_t)K2 * 8, st>>>((const u64 *)ws_partial.p, (size_t)pstride,
+                                                                                  (const u32 *)ws_pcnt.p, (u32)pstride, K2, K2,
+                                                                                  (u64 *)ws_akeys.p, nullptr);
+        HAC_HIP(hipGetLastError());
         rescore_kernel<<<dim3((unsigned)nq), dim3(256), 0, st>>>(a, (const u64 *)ws_akeys.p, (const float *)ws_delta.p, K2, k, keys_out,
                                                                (u32 *)ws_fail.p, (u32 *)ws_stat.p);
         HAC_HIP(hipGetLastError());

@@ -383,3 +383,105 @@ def test_resident_corpus_many_searches(tmp_path, oracle):
         D, I = rc.search(q[sl], 100)
         np.testing.assert_array_equal(I, ids[oI[sl]])
         np.testing.assert_array_equal(D, oD[sl].astype(np.float64))
+
+
+# ---------------------------------------------------------------------------------------------
+# split-bf16 prefilter (scan_split.inc): an accelerator with a certificate; results must be the
+# exact kernels' results bit for bit, whether the certificate holds or the query falls back.
+def _plan_fields(idx):
+    plan = idx.last_plan()
+    assert plan.startswith("split:"), plan
+    fb = plan.split("fallback=")[1].split()[0]
+    nfail, nq = (int(v) for v in fb.split("/"))
+    ratio = float(plan.split("err/bound=")[1].split()[0])
+    return nfail, nq, ratio
+
+
+@pytest.mark.parametrize("n,nq,k", [(4000, 64, 100), (20000, 130, 10), (20000, 100, 192), (70001, 200, 1), (150000, 300, 100)])
+def test_split_prefilter_equals_exact_and_oracle(n, nq, k, oracle, monkeypatch):
+    """Forced through the prefilter (HAC_SPLIT=1) vs forced off (HAC_SPLIT=0): identical ids and
+    scores; on random data the certificate holds for (nearly) every query and the measured
+    |approx - canonical| stays far inside the proven bound."""
+    from haconvdr_amd.index import FlatIPIndex
+    x, q, _ = cases.search_case_inputs("gauss", 7000 + n, n, nq)
+    idx = FlatIPIndex(768)
+    idx.add(x[: n // 3])           # three segments, the last group partial
+    idx.add(x[n // 3: n // 2])
+    idx.add(x[n // 2:])
+    monkeypatch.setenv("HAC_SPLIT", "0")
+    D0, I0 = idx.search(q, k)
+    assert not idx.last_plan().startswith("split:")
+    monkeypatch.setenv("HAC_SPLIT", "1")
+    D1, I1 = idx.search(q, k)
+    nfail, nq_, ratio = _plan_fields(idx)
+    assert nq_ == nq and nfail <= nq // 20, idx.last_plan()
+    assert ratio < 0.05, idx.last_plan()
+    assert_same(D1, I1, D0, I0)
+    sel = np.arange(0, nq, max(1, nq // 16))
+    assert_same(D1[sel], I1[sel], *oracle.flat_ip_search(x, q[sel], k))
+
+
+def test_split_prefilter_unsupported_shapes_take_the_exact_kernels(monkeypatch):
+    from haconvdr_amd.index import FlatIPIndex
+    x, q, _ = cases.search_case_inputs("gauss", 91, 3000, 64)
+    idx = FlatIPIndex(768)
+    idx.add(x)
+    monkeypatch.setenv("HAC_SPLIT", "1")
+    idx.search(q, 193)                       # k beyond the candidate lists' margin
+    assert not idx.last_plan().startswith("split:")
+    idx.reset()
+    idx.add(x[:100])                         # fewer rows than candidate slots
+    idx.search(q, 10)
+    assert not idx.last_plan().startswith("split:")
+
+
+def test_split_prefilter_ties_and_degenerate_data_fall_back(oracle, monkeypatch):
+    """Data the certificate cannot vouch for: exact duplicates around the k-th score, all-equal scores,
+    NaN / Inf rows, a zero query.  Those queries are re-run by the exact kernels; the answer is the oracle's."""
+    from haconvdr_amd.index import FlatIPIndex
+    monkeypatch.setenv("HAC_SPLIT", "1")
+    x, q, _ = cases.search_case_inputs("gauss", 4242, 6000, 80)
+    # (a) every row duplicated 600 times: ties far wider than the candidate lists
+    xd = np.tile(x[:10], (600, 1))
+    idx = FlatIPIndex(768)
+    idx.add(xd)
+    D, I = idx.search(q, 100)
+    nfail, _, _ = _plan_fields(idx)
+    assert nfail == len(q)
+    assert_same(D, I, *oracle.flat_ip_search(xd, q, 100))
+    # (b) NaN and Inf rows poison the norm bound: everything falls back, NaN rows are never returned
+    xn = x.copy()
+    xn[17, 5] = np.nan
+    xn[4000, 700] = np.inf
+    idx.reset()
+    idx.add(xn)
+    D, I = idx.search(q, 50)
+    nfail, _, _ = _plan_fields(idx)
+    assert nfail == len(q)
+    assert_same(D, I, *oracle.flat_ip_search(xn, q, 50))
+    # (c) after reset the bound is rebuilt from the new rows only
+    idx.reset()
+    idx.add(x)
+    qz = q.copy()
+    qz[3] = 0.0                               # zero query: all scores tie at 0
+    D, I = idx.search(qz, 100)
+    nfail, _, ratio = _plan_fields(idx)
+    assert 1 <= nfail <= 4 and ratio < 0.05, idx.last_plan()
+    assert_same(D, I, *oracle.flat_ip_search(x, qz, 100))
+
+
+def test_split_prefilter_keys_with_pos_base_and_shards(oracle, monkeypatch):
+    """search_keys (the sharded / multi-block entry) through the prefilter: global positions, merge."""
+    import torch
+    from haconvdr_amd.index import FlatIPIndex, merge_keys, keys_to_results
+    monkeypatch.setenv("HAC_SPLIT", "1")
+    x, q, _ = cases.search_case_inputs("gauss", 31337, 30000, 96)
+    h1, h2 = FlatIPIndex(768), FlatIPIndex(768)
+    h1.add(x[:13000])
+    h2.add(x[13000:])
+    qt = torch.from_numpy(q).cuda()
+    k1 = h1.search_keys_tensor(qt, 100, pos_base=0)
+    assert h1.last_plan().startswith("split:")
+    k2 = h2.search_keys_tensor(qt, 100, pos_base=13000)
+    D, I = keys_to_results(merge_keys(torch.stack([k1, k2])))
+    assert_same(D.cpu().numpy(), I.cpu().numpy(), *oracle.flat_ip_search(x, q, 100))
