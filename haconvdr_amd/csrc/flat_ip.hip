@@ -845,7 +845,8 @@ struct DeviceIndex {
                                 (const void *)scanq_kernel<3, 8>, (const void *)scanq_kernel<4, 8>};
             for (const void *f : fq) HAC_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
             HAC_HIP(hipFuncSetAttribute((const void *)sample_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * 1024)));
-            HAC_HIP(hipFuncSetAttribute((const void *)scanb_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+            HAC_HIP(hipFuncSetAttribute((const void *)scanh_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+            HAC_HIP(hipFuncSetAttribute((const void *)scanh_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
             attr_done[device] = true;
         }
         return HAC_OK;
@@ -1245,17 +1246,19 @@ struct DeviceIndex {
 
     int search_keys_split(const float *q_dev, int64_t nq, int k, u64 *keys_out, u32 pos_base, hipStream_t st) {
         const int K2 = SPLIT_K2, C2 = SPLIT_C2;
+        int terms = 3;   // fp16 products per score: 3 (hi/lo split, error ~2.5e-4 |q||x|) or 1 (~1e-3 |q||x|, a third of the MFMA work)
+        if (const char *e = getenv("HAC_SPLIT_TERMS")) terms = (e[0] == '1') ? 1 : 3;
         HAC_TRY(upload_segs(st));
         const u32 G = (u32)((ntotal + GROUP_ROWS - 1) / GROUP_ROWS);
-        const int n_qtiles = (int)((nq + SB_NQ - 1) / SB_NQ);
-        const int64_t nq_pad = (int64_t)n_qtiles * SB_NQ;
+        const int n_qtiles = (int)((nq + SH_NQ - 1) / SH_NQ);
+        const int64_t nq_pad = (int64_t)n_qtiles * SH_NQ;
         long P = std::max<long>(1, n_cu / n_qtiles);
         if (P >= 8) P = P / 8 * 8;  // same-row workgroups of different query tiles share an XCD (L2)
-        P = std::max<long>(1, std::min<long>(P, (G + SB_W - 1) / SB_W));
-        const size_t lds = scanb_lds_bytes();
-        HAC_TRY(ws_qsplit.reserve((size_t)nq_pad * d * 4));
+        P = std::max<long>(1, std::min<long>(P, (G + SH_GPR - 1) / SH_GPR));
+        const size_t lds = terms == 3 ? ShCfg<3>::LDS : ShCfg<1>::LDS;
+        HAC_TRY(ws_qsplit.reserve((size_t)nq_pad * d * 2 * (terms == 3 ? 2 : 1)));
         HAC_TRY(ws_delta.reserve((size_t)nq_pad * 4));
-        HAC_TRY(ws_cand.reserve((size_t)P * n_qtiles * SB_NQ * C2 * 8));
+        HAC_TRY(ws_cand.reserve((size_t)P * n_qtiles * SH_NQ * C2 * 8));
         const long pstride = (long)(P + 1) * K2;
         HAC_TRY(ws_partial.reserve((size_t)nq * pstride * 8));
         HAC_TRY(ws_pcnt.reserve((size_t)nq * 4));
@@ -1266,8 +1269,8 @@ struct DeviceIndex {
         HAC_TRY(ws_thr.reserve((size_t)nq * 8));
         HAC_TRY(fb_reserve((size_t)nq + 8));
 
-        split_queries_kernel<<<dim3((unsigned)nq_pad), dim3(192), 0, st>>>(reinterpret_cast<const float4 *>(q_dev), (int)nq, K4,
-                                                                          (const u32 *)ws_norm.p, (bf16 *)ws_qsplit.p,
+        split_queries_kernel<<<dim3((unsigned)nq_pad), dim3(192), 0, st>>>(reinterpret_cast<const float4 *>(q_dev), (int)nq, K4, terms,
+                                                                          (const u32 *)ws_norm.p, (h16 *)ws_qsplit.p,
                                                                           (float *)ws_delta.p);
         HAC_HIP(hipGetLastError());
 
@@ -1325,7 +1328,7 @@ struct DeviceIndex {
         // Two phases.  The first sixteenth of the corpus runs on the sample's (loose) thresholds; its merged K2-th
         // scores then bound the rest sharply enough (K2 rows out of N/16 pass) that candidate lists hardly
         // ever fill: with the loose thresholds alone, list compactions cost as much as half the MFMA work.
-        const u32 round_groups = (u32)P * SB_W;
+        const u32 round_groups = (u32)P * SH_GPR;
         // at least ~48k rows (K2 of them = 0.5 % pass the second phase's thresholds), a sixteenth of a large index
         u32 GA = (std::max<u32>(G / 16u, 768u) + round_groups - 1u) / round_groups * round_groups;
         if (GA * 2u > G) GA = 0;   // small index: one phase
@@ -1334,7 +1337,8 @@ struct DeviceIndex {
             a.n_items = GA;
             a.thr_init = thr_init;
             sp.thr_is_approx = 0;
-            scanb_kernel<<<dim3((unsigned)P, (unsigned)n_qtiles), dim3(SB_W * 64), lds, st>>>(a, sp);
+            if (terms == 3) scanh_kernel<3><<<dim3((unsigned)P, (unsigned)n_qtiles), dim3(SH_W * 64), lds, st>>>(a, sp);
+            else scanh_kernel<1><<<dim3((unsigned)P, (unsigned)n_qtiles), dim3(SH_W * 64), lds, st>>>(a, sp);
             HAC_HIP(hipGetLastError());
             select_keys_kernel<<<dim3((unsigned)nq), dim3(256), (size_t)K2 * 8, st>>>((const u64 *)ws_partial.p, (size_t)pstride,
                                                                                       (const u32 *)ws_pcnt.p, (u32)pstride, K2, K2,
@@ -1348,7 +1352,8 @@ struct DeviceIndex {
         a.n_items = G - GA;
         a.thr_init = GA ? thr_b : thr_init;
         sp.thr_is_approx = GA ? 1 : 0;
-        scanb_kernel<<<dim3((unsigned)P, (unsigned)n_qtiles), dim3(SB_W * 64), lds, st>>>(a, sp);
+        if (terms == 3) scanh_kernel<3><<<dim3((unsigned)P, (unsigned)n_qtiles), dim3(SH_W * 64), lds, st>>>(a, sp);
+        else scanh_kernel<1><<<dim3((unsigned)P, (unsigned)n_qtiles), dim3(SH_W * 64), lds, st>>>(a, sp);
         HAC_HIP(hipGetLastError());
         if (profiling) {
             HAC_HIP(hipEventRecord(ev_pool[ev_used].second, st));
@@ -1369,8 +1374,8 @@ struct DeviceIndex {
         std::memcpy(&maxratio, &h_fb[1], 4);
         ++split_searches;
         split_fallback_queries += nfail;
-        snprintf(last_plan, sizeof last_plan, "split: scanb_kernel grid=(%ld,%d) NQ=%d K2=%d lds=%zu seed=%d fallback=%u/%lld err/bound=%.3g",
-                 P, n_qtiles, SB_NQ, K2, lds, thr_init ? 1 : 0, nfail, (long long)nq, (double)maxratio);
+        snprintf(last_plan, sizeof last_plan, "split: scanh_kernel<%d> grid=(%ld,%d) NQ=%d K2=%d lds=%zu seed=%d fallback=%u/%lld err/bound=%.3g",
+                 terms, P, n_qtiles, SH_NQ, K2, lds, thr_init ? 1 : 0, nfail, (long long)nq, (double)maxratio);
         if (nfail == 0) return HAC_OK;
 
         // certificate failed for some queries: the exact kernels decide those
