@@ -792,7 +792,8 @@ struct DeviceIndex {
     bool segs_dirty = true;
     GrowBuf ws_partial, ws_pcnt, ws_seedkeys, ws_thr, ws_thrglob, ws_q, ws_qt, ws_keys, ws_D, ws_I, ws_stage[2];
     // split-bf16 prefilter path (scan_split.inc)
-    GrowBuf ws_norm, ws_qsplit, ws_delta, ws_cand, ws_akeys, ws_fail, ws_stat, ws_fbidx, ws_fbq, ws_fbkeys;
+    GrowBuf ws_norm, ws_qsplit, ws_delta, ws_cand, ws_akeys, ws_fail, ws_stat;
+    GrowBuf ws_fbidx[2], ws_fbq[2], ws_fbkeys[2];   // per cascade level: failed queries, their matrix, their keys
     u32 *h_fb = nullptr;       // pinned: [0] failed queries, [1] max |s~ - s| / delta (float bits), [2..] flags / indices
     size_t h_fb_words = 0;
     long split_searches = 0, split_fallback_queries = 0;
@@ -862,8 +863,8 @@ struct DeviceIndex {
         if (h_segs) (void)hipHostFree(h_segs);
         if (h_pin) (void)hipHostFree(h_pin);
         for (GrowBuf *b : {&ws_partial, &ws_pcnt, &ws_seedkeys, &ws_thr, &ws_thrglob, &ws_q, &ws_qt, &ws_keys, &ws_D, &ws_I, &ws_stage[0],
-                           &ws_stage[1], &ws_norm, &ws_qsplit, &ws_delta, &ws_cand, &ws_akeys, &ws_fail, &ws_stat, &ws_fbidx, &ws_fbq,
-                           &ws_fbkeys})
+                           &ws_stage[1], &ws_norm, &ws_qsplit, &ws_delta, &ws_cand, &ws_akeys, &ws_fail, &ws_stat, &ws_fbidx[0], &ws_fbidx[1],
+                           &ws_fbq[0], &ws_fbq[1], &ws_fbkeys[0], &ws_fbkeys[1]})
             b->release();
         if (h_fb) (void)hipHostFree(h_fb);
         for (int i = 0; i < 2; ++i) {
@@ -1023,7 +1024,7 @@ struct DeviceIndex {
         return HAC_OK;
     }
     int nseg_live = 0;
-    char last_plan[160] = "none";
+    char last_plan[320] = "none";
 
     struct Plan {
         int kind;  // 0: scan16 (<=16 queries per workgroup, Q resident in LDS)   1: scanq<NT,W>
@@ -1244,10 +1245,15 @@ struct DeviceIndex {
         return HAC_OK;
     }
 
-    int search_keys_split(const float *q_dev, int64_t nq, int k, u64 *keys_out, u32 pos_base, hipStream_t st) {
+    // Cascade: one fp16 product per score (|s~ - s| ~ 1.2e-3 |q||x| proven) decides every query whose candidate
+    // list it can certify; if many fail, three products (hi/lo split, ~2.8e-4 |q||x|, three times the MFMA work)
+    // retry those; whatever is left goes to the exact fp32 kernels.  level 0 -> terms 1, level 1 -> terms 3.
+    int search_keys_split(const float *q_dev, int64_t nq, int k, u64 *keys_out, u32 pos_base, hipStream_t st, int level = 0) {
         const int K2 = SPLIT_K2, C2 = SPLIT_C2;
-        int terms = 3;   // fp16 products per score: 3 (hi/lo split, error ~2.5e-4 |q||x|) or 1 (~1e-3 |q||x|, a third of the MFMA work)
-        if (const char *e = getenv("HAC_SPLIT_TERMS")) terms = (e[0] == '1') ? 1 : 3;
+        int terms = level == 0 ? 1 : 3;
+        if (const char *e = getenv("HAC_SPLIT_TERMS")) {   // tests: pin the first level
+            if (level == 0 && e[0] == '3') terms = 3;
+        }
         HAC_TRY(upload_segs(st));
         const u32 G = (u32)((ntotal + GROUP_ROWS - 1) / GROUP_ROWS);
         const int n_qtiles = (int)((nq + SH_NQ - 1) / SH_NQ);
@@ -1372,13 +1378,14 @@ struct DeviceIndex {
         const u32 nfail = h_fb[0];
         float maxratio;
         std::memcpy(&maxratio, &h_fb[1], 4);
-        ++split_searches;
-        split_fallback_queries += nfail;
-        snprintf(last_plan, sizeof last_plan, "split: scanh_kernel<%d> grid=(%ld,%d) NQ=%d K2=%d lds=%zu seed=%d fallback=%u/%lld err/bound=%.3g",
+        if (level == 0) ++split_searches;
+        char plan_here[sizeof last_plan];
+        snprintf(plan_here, sizeof plan_here, "split: scanh_kernel<%d> grid=(%ld,%d) NQ=%d K2=%d lds=%zu seed=%d fallback=%u/%lld err/bound=%.3g",
                  terms, P, n_qtiles, SH_NQ, K2, lds, thr_init ? 1 : 0, nfail, (long long)nq, (double)maxratio);
+        std::memcpy(last_plan, plan_here, sizeof last_plan);
         if (nfail == 0) return HAC_OK;
 
-        // certificate failed for some queries: the exact kernels decide those
+        // certificate failed for some queries: the next level decides those
         HAC_HIP(hipMemcpyAsync(h_fb + 8, ws_fail.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
         HAC_HIP(hipStreamSynchronize(st));
         std::vector<int> idx;
@@ -1387,25 +1394,34 @@ struct DeviceIndex {
             if (h_fb[8 + i]) idx.push_back((int)i);
         const int nf = (int)idx.size();
         std::memcpy(h_fb + 8, idx.data(), (size_t)nf * 4);
-        HAC_TRY(ws_fbidx.reserve((size_t)nf * 4));
-        HAC_TRY(ws_fbq.reserve((size_t)nf * d * 4));
-        HAC_TRY(ws_fbkeys.reserve((size_t)nf * k * 8));
-        HAC_HIP(hipMemcpyAsync(ws_fbidx.p, h_fb + 8, (size_t)nf * 4, hipMemcpyHostToDevice, st));
+        GrowBuf &fbidx = ws_fbidx[level & 1], &fbq = ws_fbq[level & 1], &fbkeys = ws_fbkeys[level & 1];
+        HAC_TRY(fbidx.reserve((size_t)nf * 4));
+        HAC_TRY(fbq.reserve((size_t)nf * d * 4));
+        HAC_TRY(fbkeys.reserve((size_t)nf * k * 8));
+        HAC_HIP(hipMemcpyAsync(fbidx.p, h_fb + 8, (size_t)nf * 4, hipMemcpyHostToDevice, st));
         gather_rows_kernel<<<dim3((unsigned)(((long)nf * K4 + 255) / 256)), dim3(256), 0, st>>>(
-            reinterpret_cast<const float4 *>(q_dev), (const int *)ws_fbidx.p, nf, K4, (float4 *)ws_fbq.p);
+            reinterpret_cast<const float4 *>(q_dev), (const int *)fbidx.p, nf, K4, (float4 *)fbq.p);
         HAC_HIP(hipGetLastError());
-        char keep_plan[sizeof last_plan];
-        std::memcpy(keep_plan, last_plan, sizeof last_plan);
+        HAC_HIP(hipStreamSynchronize(st));   // h_fb is reused by the next level
         const bool prof = profiling;
-        profiling = false;   // one timed kernel per search: the prefilter
-        const int rc = search_keys_exact((const float *)ws_fbq.p, nf, k, (u64 *)ws_fbkeys.p, pos_base, st);
+        profiling = false;   // one timed kernel per search: the first prefilter
+        int rc;
+        if (terms == 1 && nf >= 64) {
+            rc = search_keys_split((const float *)fbq.p, nf, k, (u64 *)fbkeys.p, pos_base, st, 1);
+            // "a;b": the second level's line after the first's
+            char both[sizeof last_plan];
+            snprintf(both, sizeof both, "%.150s ; then %.140s", plan_here, last_plan + 7);
+            std::memcpy(plan_here, both, sizeof plan_here);
+        } else {
+            split_fallback_queries += nf;
+            rc = search_keys_exact((const float *)fbq.p, nf, k, (u64 *)fbkeys.p, pos_base, st);
+        }
         profiling = prof;
-        std::memcpy(last_plan, keep_plan, sizeof last_plan);
+        std::memcpy(last_plan, plan_here, sizeof last_plan);
         HAC_TRY(rc);
-        scatter_keys_kernel<<<dim3((unsigned)(((long)nf * k + 255) / 256)), dim3(256), 0, st>>>((const u64 *)ws_fbkeys.p,
-                                                                                              (const int *)ws_fbidx.p, nf, k, keys_out);
+        scatter_keys_kernel<<<dim3((unsigned)(((long)nf * k + 255) / 256)), dim3(256), 0, st>>>((const u64 *)fbkeys.p,
+                                                                                              (const int *)fbidx.p, nf, k, keys_out);
         HAC_HIP(hipGetLastError());
-        // h_fb is reused by the next search: the index upload above must have been consumed
         HAC_HIP(hipStreamSynchronize(st));
         return HAC_OK;
     }
