@@ -303,6 +303,19 @@ def main():
                 enc(pid_t, m)
             torch.cuda.synchronize()
             pres[name] = Bp / ((time.perf_counter() - t1) / 3)
+        # queries with their real lengths (uniform in [64, 512], padded to 512 with a prefix mask):
+        # the reference computes the padding too; this encoder only the real tokens (varlen packing)
+        qlens = 64 + (synth.uniform_u32(0x91E45 + rank, nq_loc) % np.uint32(max(1, Lq - 64 + 1))).astype(np.int64)
+        qvar_mask = (torch.arange(Lq, device=dev)[None, :] < torch.from_numpy(qlens).to(dev)[:, None]).to(torch.int64)
+        for _ in range(2):
+            enc(ids_t, qvar_mask)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            enc(ids_t, qvar_mask)
+        torch.cuda.synchronize()
+        encode["queries_varlen"] = {"queries_per_sec_per_gpu": round(nq_loc / ((time.perf_counter() - t1) / 3), 1),
+                                    "mean_len": round(float(qlens.mean()), 1), "lens": "uniform in [64, 512], prefix mask"}
         encode["passages_L384"] = {"docs_per_sec_per_gpu_padded": round(pres["padded"], 1),
                                    "docs_per_sec_per_gpu_varlen": round(pres["varlen"], 1),
                                    "mean_len_varlen": round(float(plens.mean()), 1), "batch": Bp}
