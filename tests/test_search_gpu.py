@@ -508,3 +508,23 @@ def test_split_prefilter_cascade_escalates_to_three_products(oracle, monkeypatch
     nfail, nq_, _ = _plan_fields(idx)
     assert nfail >= 64 and "then scanh_kernel<3>" in plan, plan
     assert_same(D, I, *oracle.flat_ip_search(x, q, 100))
+
+
+@pytest.mark.parametrize("d", [64, 512, 1024])
+def test_split_prefilter_other_dimensions(d, oracle, monkeypatch):
+    """The prefilter is generic in d (multiples of 64 up to HAC_MAX_D): same answers as the exact kernels
+    and the oracle; clustered rows (many near-ties) exercise the cascade on the way."""
+    from haconvdr_amd.index import FlatIPIndex
+    rng = np.random.default_rng(1000 + d)
+    centers = rng.standard_normal((40, d)).astype(np.float32)
+    x = (centers[rng.integers(0, 40, 9000)] + 0.05 * rng.standard_normal((9000, d))).astype(np.float32)
+    q = rng.standard_normal((150, d)).astype(np.float32)
+    idx = FlatIPIndex(d)
+    idx.add(x)
+    monkeypatch.setenv("HAC_SPLIT", "0")
+    D0, I0 = idx.search(q, 50)
+    monkeypatch.setenv("HAC_SPLIT", "1")
+    D1, I1 = idx.search(q, 50)
+    assert idx.last_plan().startswith("split:"), idx.last_plan()
+    assert_same(D1, I1, D0, I0)
+    assert_same(D1[:8], I1[:8], *oracle.flat_ip_search(x, q[:8], 50))
