@@ -76,7 +76,17 @@ int hac_index_add_device(hac_index *idx, const float *x_dev, int64_t n, void *hi
 
 /* D, I = index.search(query_embeddings, topN) — src/test_HAConvDR_topiocqa.py:102.
  * q: host float32 [nq, d]; D: host float32 [nq, k]; I: host int64 [nq, k]
- * (rows numbered by insertion order since the last reset).  Synchronous. */
+ * (rows numbered by insertion order since the last reset).  Synchronous.
+ *
+ * Result contract of every search entry point: score = k-ordered fp32 fma chain, order =
+ * (score desc, row asc), NaN scores never returned, short lists padded -FLT_MAX / -1.
+ * With many (query, row) pairs (>= 48 queries, >= 1e8 pairs, k <= 192, d % 64 == 0) the
+ * rows are first screened on the fp16 matrix pipe under a proven error bound, the few
+ * candidates are rescored exactly and each query's list is certified complete; queries
+ * that cannot be certified are searched again by the exact fp32 kernels.
+ * The results are the same bits either way.  Environment: HAC_SPLIT=0 disables the
+ * screen, HAC_SPLIT=1 applies it whenever the shape allows (tests).  That path reads a
+ * small status word back, so the *_device variants synchronize the stream they are given. */
 int hac_index_search(hac_index *idx, const float *q, int64_t nq, int k, float *D, int64_t *I);
 /* Device/stream variant (single-device index).  id_map_dev (optional, int64
  * [ntotal]) maps row -> external id, fusing `passage_embedding2id[I]` (:110). */
