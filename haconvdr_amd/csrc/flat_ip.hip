@@ -1426,14 +1426,25 @@ struct DeviceIndex {
         return HAC_OK;
     }
 
-    // keys_out: device u64 [nq][k], canonical (score desc, row asc) keys of the k best rows per query
+    // keys_out: device u64 [nq][k], canonical (score desc, row asc) keys of the k best rows per query.
+    // Large query sets (the reference searches a whole test set per block: 2.5k - 16k queries) go through
+    // in chunks of 1024: four 256-query tiles x 64 row streams (or 16 x 16 for the exact kernels) fill the
+    // chip with same-row workgroups sharing an XCD; one launch over 33 query tiles does neither.
+    static constexpr int64_t QUERY_CHUNK = 1024;
     int search_keys(const float *q_dev, int64_t nq, int k, u64 *keys_out, u32 pos_base, hipStream_t st) {
-        if (nq > 0 && ntotal > 0 && split_eligible(nq, k)) {
+        if (nq > 0 && ntotal > 0) {
             if (((uintptr_t)q_dev & 15) != 0) return fail(HAC_ERR_INVALID, "search: query pointer must be 16-byte aligned");
             if ((uint64_t)pos_base + (uint64_t)ntotal > 0xFFFFFFFFull) return fail(HAC_ERR_UNSUPPORTED, "row positions exceed 32 bits");
-            return search_keys_split(q_dev, nq, k, keys_out, pos_base, st);
         }
-        return search_keys_exact(q_dev, nq, k, keys_out, pos_base, st);
+        for (int64_t off = 0; off < nq || off == 0; off += QUERY_CHUNK) {
+            const int64_t n = std::min<int64_t>(QUERY_CHUNK, nq - off);
+            const float *qc = q_dev + (size_t)off * d;
+            u64 *kc = keys_out + (size_t)off * k;
+            if (n > 0 && ntotal > 0 && split_eligible(n, k)) HAC_TRY(search_keys_split(qc, n, k, kc, pos_base, st));
+            else HAC_TRY(search_keys_exact(qc, n, k, kc, pos_base, st));
+            if (nq == 0) break;
+        }
+        return HAC_OK;
     }
 };
 

@@ -528,3 +528,19 @@ def test_split_prefilter_other_dimensions(d, oracle, monkeypatch):
     assert idx.last_plan().startswith("split:"), idx.last_plan()
     assert_same(D1, I1, D0, I0)
     assert_same(D1[:8], I1[:8], *oracle.flat_ip_search(x, q[:8], 50))
+
+
+def test_large_query_sets_are_chunked(oracle, monkeypatch):
+    """The reference searches a whole test set per block (thousands of queries, :102): the library walks
+    them in chunks of 1024; chunk boundaries (1024, 2048, a 452-query tail) must not show in the results."""
+    from haconvdr_amd.index import FlatIPIndex
+    x, q, _ = cases.search_case_inputs("gauss", 777, 40000, 2500)
+    idx = FlatIPIndex(768)
+    idx.add(x)
+    D1, I1 = idx.search(q, 20)                # default policy: prefilter per chunk (40k x 1024 pairs < 1e8 -> exact kernels)
+    monkeypatch.setenv("HAC_SPLIT", "1")
+    D2, I2 = idx.search(q, 20)
+    assert idx.last_plan().startswith("split:")
+    assert_same(D2, I2, D1, I1)
+    sel = np.array([0, 1, 1022, 1023, 1024, 1025, 2047, 2048, 2049, 2498, 2499])
+    assert_same(D1[sel], I1[sel], *oracle.flat_ip_search(x, q[sel], 20))
