@@ -115,3 +115,29 @@ def test_trec_writer_matches_reference(tmp_path):
     args = argparse.Namespace(top_k=int(g["topN"]), qrel_output_path=str(tmp_path), output_trec_file="run.trec")
     path = output_test_res([str(q) for q in g["qids"]], g["score_mat"], g["pid_mat"], [int(x) for x in g["offset2pid"]], args)
     assert open(path).read() == str(g["trec_text"])
+
+
+def test_trec_metrics_hand_worked(tmp_path):
+    """print_trec_res restated with trec_eval's definitions (pytrec_eval is absent: parity unpinned).
+    Two queries, hand-computed: q1 relevant {a: 2, b: 1}, run ranks [x, a, b, y]; q2 relevant {c: 1}, run
+    ranks [c, z]; q3 has a run but no judgement (ignored)."""
+    import math
+    from haconvdr_amd.trec import print_trec_res
+    qrel = tmp_path / "qrel.txt"
+    run = tmp_path / "run.trec"
+    qrel.write_text("q1 0 a 2\nq1 0 b 1\nq1 0 x 0\nq2 0 c 1\n")
+    lines = []
+    for qid, docs in (("q1", ["x", "a", "b", "y"]), ("q2", ["c", "z"]), ("q3", ["a"])):
+        for i, d in enumerate(docs):
+            lines.append(f"{qid} Q0 {d} {i + 1} {200 - i - 1} {1.0 - 0.1 * i} ance\n")
+    run.write_text("".join(lines))
+    res = print_trec_res(str(run), str(qrel), rel_threshold=1)
+    mrr = (1 / 2 + 1 / 1) / 2
+    ndcg_q1 = (2 / math.log2(3) + 1 / math.log2(4)) / (2 / math.log2(2) + 1 / math.log2(3))
+    assert res["MRR"] == round(mrr * 100, 5)
+    assert res["NDCG@3"] == round((ndcg_q1 + 1.0) / 2 * 100, 5)
+    assert res["Recall@10"] == 100.0 and res["Recall@100"] == 100.0
+    # graded judgements below the threshold count for NDCG but not for MRR / recall
+    res2 = print_trec_res(str(run), str(qrel), rel_threshold=2)
+    assert res2["MRR"] == round((1 / 2 + 0.0) / 2 * 100, 5)
+    assert res2["Recall@10"] == round((1.0 + 0.0) / 2 * 100, 5)
