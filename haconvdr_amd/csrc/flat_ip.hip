@@ -846,8 +846,9 @@ struct DeviceIndex {
                                 (const void *)scanq_kernel<3, 8>, (const void *)scanq_kernel<4, 8>};
             for (const void *f : fq) HAC_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
             HAC_HIP(hipFuncSetAttribute((const void *)sample_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * 1024)));
-            HAC_HIP(hipFuncSetAttribute((const void *)scanh_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
-            HAC_HIP(hipFuncSetAttribute((const void *)scanh_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+            const void *fh[] = {(const void *)scanh_kernel<1, false>, (const void *)scanh_kernel<3, false>,
+                                (const void *)scanh_kernel<1, true>, (const void *)scanh_kernel<3, true>};
+            for (const void *f : fh) HAC_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
             attr_done[device] = true;
         }
         return HAC_OK;
@@ -1265,14 +1266,14 @@ struct DeviceIndex {
         HAC_TRY(ws_qsplit.reserve((size_t)nq_pad * d * 2 * (terms == 3 ? 2 : 1)));
         HAC_TRY(ws_delta.reserve((size_t)nq_pad * 4));
         HAC_TRY(ws_cand.reserve((size_t)P * n_qtiles * SH_NQ * C2 * 8));
-        const long pstride = (long)(P + 1) * K2;
+        const long pstride = (long)P * K2;
         HAC_TRY(ws_partial.reserve((size_t)nq * pstride * 8));
         HAC_TRY(ws_pcnt.reserve((size_t)nq * 4));
         HAC_TRY(ws_thrglob.reserve((size_t)nq_pad * 4));
         HAC_TRY(ws_akeys.reserve((size_t)nq * K2 * 8));
         HAC_TRY(ws_fail.reserve((size_t)nq * 4));
         HAC_TRY(ws_stat.reserve(16));
-        HAC_TRY(ws_thr.reserve((size_t)nq * 8));
+        HAC_TRY(ws_thr.reserve((size_t)nq * 4));
         HAC_TRY(fb_reserve((size_t)nq + 8));
 
         split_queries_kernel<<<dim3((unsigned)nq_pad), dim3(192), 0, st>>>(reinterpret_cast<const float4 *>(q_dev), (int)nq, K4, terms,
@@ -1288,26 +1289,8 @@ struct DeviceIndex {
         a.K4 = K4;
         a.n_rows = (long)ntotal;
         a.pos_base = pos_base;
-        // seed: a lower bound of every query's K2-th canonical score (exact fp32 sample, as in the exact path)
-        float *thr_a = (float *)ws_thr.p, *thr_b = thr_a + nq;
-        const float *thr_init = nullptr;
-        const u32 n_sample = std::max<u32>(std::max<u32>(64u, G / 128u), ((u32)K2 + 1u) / 2u);
-        if (G >= 4u * n_sample) {
-            const u32 S = 4u * n_sample;
-            HAC_TRY(ws_seedkeys.reserve((size_t)nq * S * 4));
-            ScanArgs sa = a;
-            sa.g_first = 0;
-            sa.g_step = G / n_sample;
-            sa.n_items = n_sample;
-            const int qt16 = (int)((nq + 15) / 16);
-            sample_scores_kernel<<<dim3((n_sample + SCAN_WAVES - 1) / SCAN_WAVES, (unsigned)qt16), dim3(SCAN_WAVES * 64),
-                                   (size_t)K4 * 16 * 16, st>>>(sa, (float *)ws_seedkeys.p, S);
-            HAC_HIP(hipGetLastError());
-            kth_select_kernel<<<dim3((unsigned)nq), dim3(256), 0, st>>>((const float *)ws_seedkeys.p, S, K2, thr_a);
-            HAC_HIP(hipGetLastError());
-            thr_init = thr_a;
-        }
         a.k = K2;
+        a.g_first = 0;
         a.g_step = 1;
         a.thr_glob = (u32 *)ws_thrglob.p;
         a.partial = (u64 *)ws_partial.p;
@@ -1319,6 +1302,7 @@ struct DeviceIndex {
         sp.C2 = C2;
         sp.K2 = K2;
         sp.pstride = pstride;
+        sp.thr_is_approx = 1;
         HAC_HIP(hipMemsetAsync(ws_pcnt.p, 0, (size_t)nq * 4, st));
         HAC_HIP(hipMemsetAsync(ws_thrglob.p, 0, (size_t)nq_pad * 4, st));
         HAC_HIP(hipMemsetAsync(ws_stat.p, 0, 16, st));
@@ -1331,35 +1315,31 @@ struct DeviceIndex {
             }
             HAC_HIP(hipEventRecord(ev_pool[ev_used].first, st));
         }
-        // Two phases.  The first sixteenth of the corpus runs on the sample's (loose) thresholds; its merged K2-th
-        // scores then bound the rest sharply enough (K2 rows out of N/16 pass) that candidate lists hardly
-        // ever fill: with the loose thresholds alone, list compactions cost as much as half the MFMA work.
+        // Seeding pass: the first sixteenth of the corpus (at least ~48k rows) is scored once just for its
+        // per-quarter maxima; their K2-th largest opens the real pass over ALL rows with thresholds that only
+        // ~K2 * 16 rows per query pass.  Without sharp opening thresholds list compactions (sorts) cost as
+        // much as half the MFMA work.
+        const dim3 grid((unsigned)P, (unsigned)n_qtiles), blk(SH_W * 64);
         const u32 round_groups = (u32)P * SH_GPR;
-        // at least ~48k rows (K2 of them = 0.5 % pass the second phase's thresholds), a sixteenth of a large index
-        u32 GA = (std::max<u32>(G / 16u, 768u) + round_groups - 1u) / round_groups * round_groups;
-        if (GA * 2u > G) GA = 0;   // small index: one phase
-        if (GA) {
-            a.g_first = 0;
+        u32 GA = std::min<u32>(G, (std::max<u32>(G / 16u, 768u) + round_groups - 1u) / round_groups * round_groups);
+        const float *thr_init = nullptr;
+        if ((size_t)4 * GA >= (size_t)K2) {
+            const u32 S = 4u * GA;
+            HAC_TRY(ws_seedkeys.reserve((size_t)nq * S * 4));
             a.n_items = GA;
-            a.thr_init = thr_init;
-            sp.thr_is_approx = 0;
-            if (terms == 3) scanh_kernel<3><<<dim3((unsigned)P, (unsigned)n_qtiles), dim3(SH_W * 64), lds, st>>>(a, sp);
-            else scanh_kernel<1><<<dim3((unsigned)P, (unsigned)n_qtiles), dim3(SH_W * 64), lds, st>>>(a, sp);
+            a.thr_init = nullptr;
+            sp.maxima = (float *)ws_seedkeys.p;
+            if (terms == 3) scanh_kernel<3, true><<<grid, blk, lds, st>>>(a, sp);
+            else scanh_kernel<1, true><<<grid, blk, lds, st>>>(a, sp);
             HAC_HIP(hipGetLastError());
-            select_keys_kernel<<<dim3((unsigned)nq), dim3(256), (size_t)K2 * 8, st>>>((const u64 *)ws_partial.p, (size_t)pstride,
-                                                                                      (const u32 *)ws_pcnt.p, (u32)pstride, K2, K2,
-                                                                                      (u64 *)ws_akeys.p, thr_b);
+            kth_select_kernel<<<dim3((unsigned)nq), dim3(256), 0, st>>>((const float *)ws_seedkeys.p, S, K2, (float *)ws_thr.p);
             HAC_HIP(hipGetLastError());
-            seed_lists_kernel<<<dim3((unsigned)((nq * K2 + 255) / 256)), dim3(256), 0, st>>>((const u64 *)ws_akeys.p, K2, pstride, (long)nq,
-                                                                                             (u64 *)ws_partial.p, (u32 *)ws_pcnt.p);
-            HAC_HIP(hipGetLastError());
+            thr_init = (const float *)ws_thr.p;
         }
-        a.g_first = GA;
-        a.n_items = G - GA;
-        a.thr_init = GA ? thr_b : thr_init;
-        sp.thr_is_approx = GA ? 1 : 0;
-        if (terms == 3) scanh_kernel<3><<<dim3((unsigned)P, (unsigned)n_qtiles), dim3(SH_W * 64), lds, st>>>(a, sp);
-        else scanh_kernel<1><<<dim3((unsigned)P, (unsigned)n_qtiles), dim3(SH_W * 64), lds, st>>>(a, sp);
+        a.n_items = G;
+        a.thr_init = thr_init;
+        if (terms == 3) scanh_kernel<3, false><<<grid, blk, lds, st>>>(a, sp);
+        else scanh_kernel<1, false><<<grid, blk, lds, st>>>(a, sp);
         HAC_HIP(hipGetLastError());
         if (profiling) {
             HAC_HIP(hipEventRecord(ev_pool[ev_used].second, st));
