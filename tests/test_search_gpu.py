@@ -544,3 +544,48 @@ def test_large_query_sets_are_chunked(oracle, monkeypatch):
     assert_same(D2, I2, D1, I1)
     sel = np.array([0, 1, 1022, 1023, 1024, 1025, 2047, 2048, 2049, 2498, 2499])
     assert_same(D1[sel], I1[sel], *oracle.flat_ip_search(x, q[sel], 20))
+
+
+@pytest.mark.parametrize("kind", ["tiny", "huge", "heavy_tail", "sparse", "offset"])
+def test_split_prefilter_value_ranges(kind, oracle, monkeypatch):
+    """fp16's range and grid under the prefilter: magnitudes down in its subnormals, up near its overflow,
+    heavy tails, mostly-zero rows, a large common offset (scores packed tightly).  Whatever the
+    certificate makes of them, the answer is the exact kernels' and the oracle's."""
+    from haconvdr_amd.index import FlatIPIndex
+    rng = np.random.default_rng({"tiny": 11, "huge": 12, "heavy_tail": 13, "sparse": 14, "offset": 15}[kind])
+    n, nq, d, k = 12000, 128, 768, 100
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    if kind == "tiny":
+        x *= np.float32(3e-5)
+        q *= np.float32(2e-4)
+    elif kind == "huge":
+        x *= np.float32(800.0)          # row norms ~22000: inside fp16's range
+        q *= np.float32(1500.0)         # query norms ~41000
+    elif kind == "heavy_tail":
+        x = (x / np.maximum(np.abs(rng.standard_normal((n, d)).astype(np.float32)), 0.05)).astype(np.float32)
+    elif kind == "sparse":
+        x *= (rng.random((n, d)) < 0.1)
+        q *= (rng.random((nq, d)) < 0.3)
+    elif kind == "offset":
+        x += np.float32(3.0)
+        q += np.float32(1.0)
+    idx = FlatIPIndex(d)
+    idx.add(x)
+    monkeypatch.setenv("HAC_SPLIT", "0")
+    D0, I0 = idx.search(q, k)
+    monkeypatch.setenv("HAC_SPLIT", "1")
+    D1, I1 = idx.search(q, k)
+    assert idx.last_plan().startswith("split:"), idx.last_plan()
+    _, _, ratio = _plan_fields(idx)
+    assert ratio <= 1.0, idx.last_plan()          # the proven bound held on every rescored candidate
+    assert_same(D1, I1, D0, I0)
+    assert_same(D1[:6], I1[:6], *oracle.flat_ip_search(x, q[:6], k))
+    # beyond fp16's range the bound is infinite: everything falls back, same answer
+    if kind == "huge":
+        idx.reset()
+        idx.add(x * np.float32(4.0))    # row norms ~88000
+        D2, I2 = idx.search(q, k)
+        nfail, nq_, _ = _plan_fields(idx)
+        assert nfail == nq_
+        assert_same(D2[:4], I2[:4], *oracle.flat_ip_search(x * np.float32(4.0), q[:4], k))
