@@ -9,13 +9,14 @@
 //     bit-identical whatever sits in masked positions); sequences are packed back to
 //     back, each padded to a multiple of 32 rows so no MFMA tile straddles two sequences.
 //   * GEMMs (QKV, attention-out, FFN up/down): bf16 operands, fp32 accumulate on
-//     v_mfma_f32_32x32x16_bf16, 128x128x64 tiles, register-staged double-buffered LDS with an
-//     XOR-swizzled image (conflict-free ds_read_b128), fused epilogues (bias, 1/8 query scale,
-//     V written in 16-key groups, erf GELU, residual add with deferred LayerNorm).
+//     v_mfma_f32_32x32x16_bf16; persistent workgroups over 256x256x64 tiles (128x128 for small
+//     batches) in XCD-aware runs; operand tiles arrive by LDS-DMA into a double-buffered
+//     XOR-swizzled image (conflict-free ds_read_b128); LDS-transposed 16-byte epilogues (bias, query
+//     scale log2(e)/8, V written in 16-key groups, erf GELU, residual add with deferred LayerNorm).
 //   * the residual stream, LayerNorm, softmax and the final head stay fp32.
-//   * attention: one wave = 32 query rows of one (sequence, head); S^T = K.Q^T so the query sits
-//     on the lane, softmax statistics are lane-local; the S^T accumulator is converted in place
-//     into the A operand of P.V (no LDS); V comes pre-transposed from the QKV epilogue.
+//   * attention: one workgroup = all query rows of one (sequence, head) with K and V resident in LDS
+//     (LDS-DMA); S^T = K.Q^T so the query sits on the lane and softmax statistics are lane-local; the
+//     S^T accumulator is, register for register, the B operand of O^T = V^T.P^T (no LDS, no shuffles).
 #include <type_traits>
 #include "hac_common.h"
 
