@@ -146,8 +146,8 @@ def main():
                     "executed_frac": round(terms * mfma_tf / PEAK_F16_MFMA_TF, 4),
                     "vs_fp32_mfma_peak": round(mfma_tf / PEAK_F32_MFMA_TF, 3),
                     "hbm_GBps_same_kernel": round(hbm_gbs, 1), "hbm_frac_same_kernel": round(hbm_gbs / PEAK_HBM_GBS, 4),
-                    "note": "kernel_ms spans both scanh launches (first sixteenth of the corpus, then the rest) and the "
-                            "candidate-list merge between them; peak = dense fp16 MFMA"}
+                    "note": "kernel_ms spans both scanh launches of a search (maxima-only seeding pass over the first sixteenth of "
+                            "the corpus, then the full pass) and the threshold selection between them; peak = dense fp16 MFMA"}
     elif mfma_bound:
         roofline = {"kernel": kname, "plan": plan, "bound": "mfma", "achieved": round(mfma_tf, 2), "peak": PEAK_F32_MFMA_TF,
                     "unit": "TFLOP/s", "frac": round(mfma_tf / PEAK_F32_MFMA_TF, 4), "traffic": traffic,

@@ -39,9 +39,9 @@ def main():
     rl, rs = pick(f, plan, "hbm_read_bytes_per_launch", "long"), pick(f, plan, "hbm_read_bytes_per_launch", "short")
     wl, ws = pick(w, plan, "hbm_write_bytes_per_launch", "long"), pick(w, plan, "hbm_write_bytes_per_launch", "short")
     out = {"rows": 1000000, "nq": 1000,
-           "kernel": plan + " (both launches of one search: first sixteenth of the corpus, then the rest)",
+           "kernel": plan + " (both launches of one search: maxima-only seeding pass over the first sixteenth of the corpus, then the full pass)",
            "hbm_read_bytes_per_launch": int(rl + rs), "hbm_write_bytes_per_launch": int(wl + ws), "hbm_bytes_per_launch": int(rl + rs + wl + ws),
-           "per_phase": {"first_sixteenth": {"read": int(rs), "write": int(ws)}, "rest": {"read": int(rl), "write": int(wl)}},
+           "per_phase": {"seeding_pass": {"read": int(rs), "write": int(ws)}, "full_pass": {"read": int(rl), "write": int(wl)}},
            "rescore_kernel": {"hbm_read_bytes_per_launch": int(pick(f, "rescore_kernel", "hbm_read_bytes_per_launch")),
                               "note": "16-byte gathers from the T64 tiles: one useful piece per 64-B sector; the x2 streaming correction does not apply to gathers, halve this figure"},
            "exact_kernels": {"kernel": "scanq_kernel<NT=2,W=8>", "hbm_read_bytes_per_launch": int(pick(f, "scanq_kernel<2, 8>", "hbm_read_bytes_per_launch"))},
