@@ -35,9 +35,10 @@ def main():
     shutil.copy(bench, pre + "bench.json")
     f = json.load(open(pre + "bench_pmc_fetch.json"))
     w = json.load(open(pre + "bench_pmc_write.json"))
-    plan = json.load(open(bench))["roofline"]["kernel"]
-    rl, rs = pick(f, plan, "hbm_read_bytes_per_launch", "long"), pick(f, plan, "hbm_read_bytes_per_launch", "short")
-    wl, ws = pick(w, plan, "hbm_write_bytes_per_launch", "long"), pick(w, plan, "hbm_write_bytes_per_launch", "short")
+    plan = json.load(open(bench))["roofline"]["kernel"]                 # "scanh_kernel<T>"
+    full, seed = plan[:-1] + ", false>", plan[:-1] + ", true>"         # the two instantiations a search launches
+    rl, rs = pick(f, full, "hbm_read_bytes_per_launch"), pick(f, seed, "hbm_read_bytes_per_launch")
+    wl, ws = pick(w, full, "hbm_write_bytes_per_launch"), pick(w, seed, "hbm_write_bytes_per_launch")
     out = {"rows": 1000000, "nq": 1000,
            "kernel": plan + " (both launches of one search: maxima-only seeding pass over the first sixteenth of the corpus, then the full pass)",
            "hbm_read_bytes_per_launch": int(rl + rs), "hbm_write_bytes_per_launch": int(wl + ws), "hbm_bytes_per_launch": int(rl + rs + wl + ws),
