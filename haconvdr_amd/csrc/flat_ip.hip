@@ -1230,7 +1230,9 @@ struct DeviceIndex {
     bool split_eligible(int64_t nq, int k) const {
         const char *e = getenv("HAC_SPLIT");   // "0": never, "1": whenever supported (tests), unset: by size
         if (e && e[0] == '0') return false;
-        if (K4 % 16 != 0 || d > HAC_MAX_D || k > SPLIT_K2 - 64 || ntotal < SPLIT_K2) return false;
+        // d % 64 == 0 (whole query slices) and at least 8 k-steps per row: the corpus ring runs 6 steps ahead and
+        // may reach into the NEXT group only
+        if (K4 % 16 != 0 || K4 < 32 || d > HAC_MAX_D || k > SPLIT_K2 - 64 || ntotal < SPLIT_K2) return false;
         if (e && e[0] == '1') return true;
         return nq >= 48 && (double)nq * (double)ntotal >= 1.0e8;
     }
