@@ -33,7 +33,11 @@ typedef __bf16 bf16;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f4v __attribute__((ext_vector_type(4)));
+#ifndef HAC_GEMM_S16
+#define HAC_GEMM_S16 1
+#endif
 
 constexpr int H = 768;        // hidden size (RoBERTa-base / ANCE)
 constexpr int NH = 12;        // heads
@@ -312,6 +316,7 @@ __global__ __launch_bounds__(TMT * 128, 2) void gemm_bf16_nt_kernel(GemmArgs g) 
     constexpr int BM = 64 * TMT, BN = BM;
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int WN = BN / 64;           // waves along N (2 or 4); 2 along M
+    constexpr bool S16 = (TMT == 4) && HAC_GEMM_S16;   // 16x16x32 MFMA form for the big tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -365,18 +370,54 @@ __global__ __launch_bounds__(TMT * 128, 2) void gemm_bf16_nt_kernel(GemmArgs g) 
     for (; tile < run_hi; tile += per_xcd) {
         const int m0 = (tile / nx) * BM, n0 = (tile % nx) * BN;
         const int next_tile = tile + per_xcd;
-        f32x16 acc[TMT][2];
+        // Two accumulator forms.  S16 (the 256^2 tile): v_mfma_f32_16x16x32_bf16, 8 x 4 tiles of 16x16 per wave;
+        // same FLOPs, LDS traffic and matrix-pipe cycles as the 32x32x16 form, but the part holds a higher
+        // clock on it (bare LDS-read + MFMA loop on random data: 1.79 vs 1.65 PF).
+        f32x16 acc[S16 ? 1 : TMT][2];
+        f32x4 acc16[S16 ? 2 * TMT : 1][4];
+        if constexpr (S16) {
 #pragma unroll
-        for (int a = 0; a < TMT; ++a)
+            for (int a = 0; a < 2 * TMT; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+                for (int b = 0; b < 4; ++b)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+                    for (int e = 0; e < 4; ++e) acc16[a][b][e] = 0.f;
+        } else {
+#pragma unroll
+            for (int a = 0; a < TMT; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+        }
 
         for (int kt = 0; kt < KT; ++kt) {
             if (kt + 1 < KT) stage(cur ^ 1, tile, kt + 1);
             else if (next_tile < run_hi) stage(cur ^ 1, next_tile, 0);
             const unsigned char *sc = smem + cur * STAGE;
+            if constexpr (S16) {
+                // lane (m = lane&15, kg = lane>>4): A/B fragment = row (tile*16 + m), chunk (4*ks32 + kg) ^ f(row);
+                // f(row) = (m >> 1) & 7 for every tile (tile rows differ by multiples of 16)
+                const int m16 = lane & 15, kg = lane >> 4, sw16 = (m16 >> 1) & 7;
+                const unsigned char *ab = sc + (wm * (32 * TMT) + m16) * 128;
+                const unsigned char *wb = sc + BM * 128 + (wn * 64 + m16) * 128;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int c = ((ks * 4 + kg) ^ sw16) << 4;
+                    bf16x8 wf16[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) wf16[j] = *reinterpret_cast<const bf16x8 *>(wb + j * 2048 + c);
+                    bf16x8 a_cur = *reinterpret_cast<const bf16x8 *>(ab + c), a_nxt = a_cur;
+#pragma unroll
+                    for (int i = 0; i < 2 * TMT; ++i) {
+                        if (i + 1 < 2 * TMT) a_nxt = *reinterpret_cast<const bf16x8 *>(ab + (i + 1) * 2048 + c);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur, wf16[j], acc16[i][j], 0, 0, 0);
+                        a_cur = a_nxt;
+                    }
+                }
+            } else {
             bf16x8 af[2][TMT], wf[2][2];
 #pragma unroll
             for (int t = 0; t < TMT; ++t) af[0][t] = *reinterpret_cast<const bf16x8 *>(sc + aoff[t] + ((hh ^ sw) << 4));
@@ -397,6 +438,7 @@ __global__ __launch_bounds__(TMT * 128, 2) void gemm_bf16_nt_kernel(GemmArgs g) 
                     for (int b = 0; b < 2; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][a], wf[ks & 1][b], acc[a][b], 0, 0, 0);
             }
+            }
             __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) here: next stage landed, this one is free
             cur ^= 1;
         }
@@ -411,6 +453,25 @@ __global__ __launch_bounds__(TMT * 128, 2) void gemm_bf16_nt_kernel(GemmArgs g) 
         if (EPI == EPI_QKV && n0 >= 2 * H) {
             // V goes out in 16-key groups ([Mp/16][768][16]) for the attention kernel's LDS-DMA: a lane holds
             // 4 consecutive tokens of one feature, i.e. 8 contiguous bytes of that layout.
+            if constexpr (S16) {
+                const int m16 = lane & 15, kg = lane >> 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = ncol0 + j * 16 + m16 - 2 * H;
+                    const float bias = g.bias[ncol0 + j * 16 + m16];
+                    const size_t mg = (size_t)(m0 + wm * (32 * TMT)) >> 4;
+#pragma unroll
+                    for (int i = 0; i < 2 * TMT; ++i) {   // tokens 16*i + 4*kg + (0..3) of the wave's rows: group i, slot 4*kg
+                        bf16x4 o;
+                        o.x = (bf16)(acc16[i][j][0] + bias);
+                        o.y = (bf16)(acc16[i][j][1] + bias);
+                        o.z = (bf16)(acc16[i][j][2] + bias);
+                        o.w = (bf16)(acc16[i][j][3] + bias);
+                        *reinterpret_cast<bf16x4 *>(g.v16 + ((mg + i) * H + n) * 16 + 4 * kg) = o;
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 const int n = ncol0 + b * 32 + r - 2 * H;
@@ -431,6 +492,11 @@ __global__ __launch_bounds__(TMT * 128, 2) void gemm_bf16_nt_kernel(GemmArgs g) 
                 }
             }
             continue;
+        }
+        float bias16[4];
+        if constexpr (S16) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bias16[j] = g.bias[ncol0 + j * 16 + (lane & 15)];
         }
 #pragma unroll
         for (int a = 0; a < TMT; ++a) {
@@ -453,12 +519,20 @@ __global__ __launch_bounds__(TMT * 128, 2) void gemm_bf16_nt_kernel(GemmArgs g) 
                         }
                     }
                 }
+                if constexpr (S16) {   // 16x16 tiles: lane (column m16 of tile j, rows 4*kg .. 4*kg+3)
+                    const int m16 = lane & 15, kg = lane >> 4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) patch[(4 * kg + e) * 64 + 16 * j + m16] = acc16[2 * a + half][j][e] + bias16[j];
+                } else {
 #pragma unroll
                 for (int e8 = 0; e8 < 8; ++e8) {
                     const int e = half * 8 + e8;
                     const int row = (e8 & 3) + 8 * (e8 >> 2) + 4 * hh;   // 0..15
                     patch[row * 64 + r] = acc[a][0][e] + bias0;
                     patch[row * 64 + 32 + r] = acc[a][1][e] + bias1;
+                }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's own LDS writes have landed
