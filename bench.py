@@ -319,6 +319,28 @@ def main():
         encode["passages_L384"] = {"docs_per_sec_per_gpu_padded": round(pres["padded"], 1),
                                    "docs_per_sec_per_gpu_varlen": round(pres["varlen"], 1),
                                    "mean_len_varlen": round(float(plens.mean()), 1), "batch": Bp}
+        # the whole passage-encoding loop of gen_doc_embeddings.py (record reader -> H2D -> encode -> block D2H ->
+        # pickle-4 block files), on a 20k-passage synthetic collection with the varlen lengths above
+        try:
+            import shutil
+            import tempfile
+            from haconvdr_amd import passages as psg_mod
+            n_p = 20000
+            tmpd = tempfile.mkdtemp(prefix="hac_bench_")
+            ptok_all, _ = synth.token_batch(0xD0C5 + rank, n_p, Lp, fixed_len=Lp)
+            plens_all = np.clip(np.rint(180.0 + 80.0 * synth.normal(0x1E46 + rank, (n_p,))), 8, Lp).astype(np.int64)
+            psg_mod.write_tokenized_passages(os.path.join(tmpd, "passages"), ptok_all.astype(np.int32), plens_all)
+            coll = psg_mod.TokenizedPassages(os.path.join(tmpd, "passages"))
+            psg_mod.encode_passages(enc, coll, os.path.join(tmpd, "warm"), per_gpu_eval_batch_size=1000)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            psg_mod.encode_passages(enc, coll, os.path.join(tmpd, "out"), per_gpu_eval_batch_size=1000)
+            torch.cuda.synchronize()
+            encode["passages_L384"]["pipeline_docs_per_sec_per_gpu"] = round(n_p / (time.perf_counter() - t1), 1)
+            encode["passages_L384"]["pipeline"] = f"encode_passages over {n_p} tokenized records (reader, H2D, encode, block files), mean len {plens_all.mean():.0f}"
+            shutil.rmtree(tmpd, ignore_errors=True)
+        except Exception as ex:   # an extra, never the headline
+            encode["passages_L384"]["pipeline_error"] = repr(ex)
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             # CPU baseline of the encoder: the fp32 oracle (torch CPU ops, all host cores) on a bounded sample
             from oracle import ance_oracle
