@@ -30,6 +30,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 namespace hac {
@@ -142,19 +143,25 @@ __device__ void block_sort_desc(u64 *buf, u32 n, int tid, int nthreads) {
 // segment rows [row0, row0 + m).  Reads are row-contiguous (256 B per 16 lanes),
 // writes are whole 1-KiB chunks; the transpose goes through a padded LDS tile.
 __global__ __launch_bounds__(256) void tile_rows_kernel(const float4 *__restrict__ src, long m, int K4,
-                                                        float4 *__restrict__ seg, long row0) {
+                                                        float4 *__restrict__ seg, long row0, u32 *__restrict__ norm2_max_bits) {
     __shared__ float4 tile[16][65];
     const int tid = threadIdx.x;
     const long gd = row0 / GROUP_ROWS + blockIdx.x;
     const long r_lo = max(row0, gd * GROUP_ROWS), r_hi = min(row0 + m, gd * GROUP_ROWS + GROUP_ROWS);
     float4 *dst = seg + gd * (long)K4 * GROUP_ROWS;
+    // |x|^2 of the rows passing through (thread = 4 rows x one of 16 column lanes): the largest row norm of
+    // the index is the scale of the half-precision prefilter's error bound (scan_split.inc)
+    float ss[4] = {0.f, 0.f, 0.f, 0.f};
     for (int k4b = 0; k4b < K4; k4b += 16) {
-        for (int i = tid; i < 1024; i += 256) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = tid + 256 * j;
             const int r = i >> 4, c = i & 15;
             const long dr = gd * GROUP_ROWS + r;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (dr >= r_lo && dr < r_hi && k4b + c < K4) v = src[(dr - row0) * K4 + k4b + c];
             tile[c][r] = v;
+            ss[j] = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, ss[j]))));
         }
         __syncthreads();
         for (int i = tid; i < 1024; i += 256) {
@@ -164,6 +171,18 @@ __global__ __launch_bounds__(256) void tile_rows_kernel(const float4 *__restrict
         }
         __syncthreads();
     }
+    u32 best = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float s = ss[j];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);   // the 16 column lanes of a row are adjacent lanes
+        const u32 b = (s != s) ? 0x7FC00000u : __float_as_uint(s);   // non-negative float bits order like the value; NaN on top
+        best = max(best, b);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = max(best, (u32)__shfl_xor((int)best, o));
+    if ((tid & 63) == 0 && best != 0u) atomicMax(norm2_max_bits, best);
 }
 
 // ------------------------------------------------------------------ scan kernel
@@ -957,11 +976,7 @@ struct DeviceIndex {
             const long row0 = (long)s.rows;
             const long g_lo = row0 / GROUP_ROWS, g_hi = (row0 + m + GROUP_ROWS - 1) / GROUP_ROWS;
             tile_rows_kernel<<<dim3((unsigned)(g_hi - g_lo)), dim3(256), 0, st>>>(
-                reinterpret_cast<const float4 *>(src_dev + (size_t)done * d), (long)m, K4, s.buf, row0);
-            HAC_HIP(hipGetLastError());
-            // largest row norm of the index (error bound of the split-bf16 prefilter)
-            row_norm_max_kernel<<<dim3((unsigned)((g_hi - g_lo + 3) / 4)), dim3(256), 0, st>>>(s.buf, K4, row0, row0 + (long)m,
-                                                                                             (u32 *)ws_norm.p);
+                reinterpret_cast<const float4 *>(src_dev + (size_t)done * d), (long)m, K4, s.buf, row0, (u32 *)ws_norm.p);
             HAC_HIP(hipGetLastError());
             s.rows += m;
             done += m;
@@ -991,7 +1006,20 @@ struct DeviceIndex {
         while (done < n) {
             const int64_t m = std::min(chunk_rows, n - done);
             if (used[slot]) HAC_HIP(hipEventSynchronize(stage_ev[slot]));
-            std::memcpy(h_stage[slot], x + (size_t)done * d, (size_t)m * d * 4);
+            {   // pageable -> pinned staging: one core copies ~12 GB/s, the link takes ~50: split the chunk over a few threads
+                const size_t bytes = (size_t)m * d * 4;
+                const char *src = reinterpret_cast<const char *>(x + (size_t)done * d);
+                char *dst = static_cast<char *>(h_stage[slot]);
+                const int nt = bytes >= (8u << 20) ? 4 : 1;
+                const size_t part = (bytes / nt + 4095) & ~(size_t)4095;
+                std::vector<std::thread> pool;
+                for (int t = 1; t < nt; ++t) {
+                    const size_t o = std::min(bytes, (size_t)t * part), e = std::min(bytes, (size_t)(t + 1) * part);
+                    if (e > o) pool.emplace_back([=] { std::memcpy(dst + o, src + o, e - o); });
+                }
+                std::memcpy(dst, src, std::min(bytes, part));
+                for (auto &th : pool) th.join();
+            }
             HAC_HIP(hipMemcpyAsync(ws_stage[slot].p, h_stage[slot], (size_t)m * d * 4, hipMemcpyHostToDevice, stream));
             // one new segment per add() at most: size it for everything that is left
             HAC_TRY(add_device_rows((const float *)ws_stage[slot].p, m, stream, n - done));
