@@ -260,8 +260,8 @@ def main():
         ids_t = torch.from_numpy(tok.astype(np.int64)).to(dev)
         mask_t = torch.ones_like(ids_t)
 
-        def e2e_step():
-            emb = enc(ids_t, mask_t)
+        def e2e_step(mask=None):
+            emb = enc(ids_t, mask_t if mask is None else mask)
             if world > 1:
                 allq = torch.empty((world * nq_loc, D_EMB), dtype=torch.float32, device=dev)
                 dist.all_gather_into_tensor(allq, emb)
@@ -373,6 +373,23 @@ def main():
             dt_e2e = float(t.item())
         end_to_end = {"queries_per_sec": round(args.nq / dt_e2e, 1), "ms_per_step": round(dt_e2e * 1e3, 3),
                       "what": f"ANCE encode of {args.nq} queries (L={Lq}, data-parallel over {world} GPU) + exact top-{args.k} over {args.rows} passages"}
+        # the same with the queries' real lengths (prefix masks, mean ~290 of 512 tokens) instead of full padding
+        e2e_step(qvar_mask)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(n_e2e):
+            e2e_step(qvar_mask)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt_v = (time.perf_counter() - t1) / n_e2e
+        if world > 1:
+            t = torch.tensor([dt_v], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_v = float(t.item())
+        end_to_end["queries_per_sec_real_lengths"] = round(args.nq / dt_v, 1)
 
     if rank == 0:
         out = {
