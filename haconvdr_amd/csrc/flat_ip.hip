@@ -1247,8 +1247,12 @@ struct DeviceIndex {
             snprintf(last_plan, sizeof last_plan, "scan16_kernel<W=%d> grid=(%d,%d) QT=%d C=%d lds=%zu seed=%d", SCAN_WAVES, pl.P,
                      pl.n_qtiles, pl.QT, pl.C, pl.lds_scan, thr_init ? 1 : 0);
         HAC_TRY(run_scan(pl, q_dev, nq, k, 0, 1, G, thr_init, pos_base, pl.P, st, profiling));
-        HAC_TRY(run_merge(pl, (const u64 *)ws_partial.p, pl.P, (size_t)k, (size_t)pl.P * k, nq, k, keys_out, nullptr, st,
-                          (const u32 *)ws_pcnt.p));
+        // the workgroups' survivors sit densely per query: radix select of the k best, one sort of k keys
+        const int np2 = (int)next_pow2((u32)k);
+        select_keys_kernel<<<dim3((unsigned)nq), dim3(256), (size_t)np2 * 8, st>>>((const u64 *)ws_partial.p, (size_t)pl.P * k,
+                                                                                   (const u32 *)ws_pcnt.p, (u32)((size_t)pl.P * k), k, np2,
+                                                                                   keys_out, nullptr);
+        HAC_HIP(hipGetLastError());
         return HAC_OK;
     }
 
