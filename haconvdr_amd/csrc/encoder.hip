@@ -194,6 +194,15 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const IT *__restrict__ id
     }
 }
 
+// rows [total, Mp) of the packed matrices: written by nobody, read by the last M tile of every GEMM
+__global__ __launch_bounds__(192) void zero_tail_rows_kernel(float *__restrict__ x_f32, bf16 *__restrict__ x_bf, const int *__restrict__ total_rows, long Mp) {
+    const long row = (long)*total_rows + blockIdx.x;
+    if (row >= Mp) return;
+    const int c = threadIdx.x * 4;
+    *reinterpret_cast<f4v *>(x_f32 + row * H + c) = (f4v){0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<bf16x4 *>(x_bf + row * H + c) = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+}
+
 // K4/K6 tail: x = LN(y) for every packed row (y already holds dense + bias + residual)
 __global__ __launch_bounds__(256) void ln_rows_kernel(const float *__restrict__ y, const int *__restrict__ total_rows,
                                                       const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
@@ -938,12 +947,12 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
     float2 *statsA = (float2 *)e->ws_stats.p, *statsF = statsA + Mp;
     bf16 *xb = (bf16 *)e->ws_xb.p, *q = (bf16 *)e->ws_q.p, *k = (bf16 *)e->ws_k.p, *vt = (bf16 *)e->ws_vt.p;
     bf16 *ctx = (bf16 *)e->ws_ctx.p, *h = (bf16 *)e->ws_h.p;
-    // dead tail rows of the last M tile feed the GEMMs: keep them finite
-    HAC_HIP(hipMemsetAsync(xb, 0, (size_t)Mp * H * 2, st));
-    HAC_HIP(hipMemsetAsync(x, 0, (size_t)Mp * H * 4, st));
     embed_ln_kernel<IT><<<dim3(L32 / 4, B), dim3(256), 0, st>>>(ids, L, s, e->word, e->posw, e->typew, e->embg, e->embb, c.ln_eps, x, xb);
     HAC_HIP(hipGetLastError());
     const int *total = s.off + B;
+    // dead tail rows of the last M tile (fewer than MT) feed the GEMMs: keep them finite
+    zero_tail_rows_kernel<<<dim3(MT), dim3(192), 0, st>>>(x, xb, total, Mp);
+    HAC_HIP(hipGetLastError());
     // tile choice: 256^2 tiles once they fill the chip, 128^2 tiles for small batches; persistent grids
     const bool big = (Mp / 256) * (H / 256) >= 128;
     const int bt = big ? 256 : 128;
