@@ -1058,8 +1058,8 @@ struct DeviceIndex {
     struct Plan {
         int kind;  // 0: scan16 (<=16 queries per workgroup, Q resident in LDS)   1: scanq<NT,W>
         int NT, W;
-        int QT, C, n_qtiles, P, Cm;
-        size_t lds_scan, lds_merge;
+        int QT, C, n_qtiles, P;
+        size_t lds_scan;
     };
 
     static size_t scanq_lds(int NQ, int C) { return (size_t)NQ * (2 * 16 * 16 + (size_t)C * 8 + 8) + 16; }
@@ -1116,8 +1116,6 @@ struct DeviceIndex {
         const long maxP = (n_items + pl.W - 1) / pl.W;
         P = std::max<long>(1, std::min(P, maxP));
         pl.P = (int)P;
-        pl.Cm = (int)next_pow2((u32)k + MERGE_THREADS);
-        pl.lds_merge = (size_t)pl.Cm * 8 + 32;
         return HAC_OK;
     }
 
@@ -1179,14 +1177,6 @@ struct DeviceIndex {
             HAC_HIP(hipEventRecord(ev_pool[ev_used].second, st));
             ++ev_used;
         }
-        return HAC_OK;
-    }
-
-    int run_merge(const Plan &pl, const u64 *lists, int L, size_t stride_l, size_t stride_q, int64_t nq, int k,
-                  u64 *out, float *kth_out, hipStream_t st, const u32 *counts = nullptr) {
-        merge_keys_kernel<<<dim3((unsigned)nq), dim3(MERGE_THREADS), pl.lds_merge, st>>>(lists, L, stride_l, stride_q, k,
-                                                                                         pl.Cm, out, kth_out, counts);
-        HAC_HIP(hipGetLastError());
         return HAC_OK;
     }
 
