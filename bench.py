@@ -117,7 +117,7 @@ def main():
 
     # ---- roofline of the dominant kernel (scan16_kernel), algorithmic figures per launch
     n_local = hi - lo
-    scan_avg_ms = float(np.mean(scan_ms)) if scan_ms else float("nan")
+    scan_avg_ms = float(np.sum(scan_ms)) / args.steps if scan_ms else float("nan")   # a search may time several chunk scans
     alg_bytes = n_local * D_EMB * 4 + args.nq * D_EMB * 4 + args.nq * args.k * 12
     alg_flops = 2.0 * args.nq * n_local * D_EMB
     hbm_gbs = alg_bytes / (scan_avg_ms * 1e-3) / 1e9
@@ -147,7 +147,8 @@ def main():
                     "vs_fp32_mfma_peak": round(mfma_tf / PEAK_F32_MFMA_TF, 3),
                     "hbm_GBps_same_kernel": round(hbm_gbs, 1), "hbm_frac_same_kernel": round(hbm_gbs / PEAK_HBM_GBS, 4),
                     "note": "kernel_ms spans both scanh launches of a search (maxima-only seeding pass over the first sixteenth of "
-                            "the corpus, then the full pass) and the threshold selection between them; peak = dense fp16 MFMA"}
+                            "the corpus, then the full pass) and the threshold selection between them, summed over the "
+                            "search's query chunks of 1024; peak = dense fp16 MFMA"}
     elif mfma_bound:
         roofline = {"kernel": kname, "plan": plan, "bound": "mfma", "achieved": round(mfma_tf, 2), "peak": PEAK_F32_MFMA_TF,
                     "unit": "TFLOP/s", "frac": round(mfma_tf / PEAK_F32_MFMA_TF, 4), "traffic": traffic,
@@ -172,7 +173,7 @@ def main():
                 De, Ie = index.search_tensor(q, args.k)
             torch.cuda.synchronize()
             dte = (time.perf_counter() - t1) / 3
-            mse = float(np.mean(index.profile_drain()))
+            mse = float(np.sum(index.profile_drain())) / 3
             index.set_profiling(False)
             tfe = alg_flops / (mse * 1e-3) / 1e12
             exact_kernels = {"plan": index.last_plan(), "kernel_ms": round(mse, 4), "search_ms": round(dte * 1e3, 4),

@@ -805,6 +805,8 @@ struct Segment {
 struct DeviceIndex {
     int d = 0, K4 = 0, device = 0, n_cu = 256;
     hipStream_t stream = nullptr;  // for the synchronous host API
+    hipStream_t stream2 = nullptr; // rescoring of one query chunk runs here, under the next chunk's scan
+    hipEvent_t ev_chunk[2] = {nullptr, nullptr}, ev_tail = nullptr;
     std::vector<Segment> segs;
     int64_t ntotal = 0;
     SegDesc *d_segs = nullptr;
@@ -849,6 +851,9 @@ struct DeviceIndex {
         HAC_HIP(hipGetDeviceProperties(&prop, device));
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         HAC_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        HAC_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) HAC_HIP(hipEventCreateWithFlags(&ev_chunk[i], hipEventDisableTiming));
+        HAC_HIP(hipEventCreateWithFlags(&ev_tail, hipEventDisableTiming));
         HAC_HIP(hipMalloc((void **)&d_segs, sizeof(SegDesc) * MAX_SEG));
         HAC_HIP(hipHostMalloc((void **)&h_segs, sizeof(SegDesc) * MAX_SEG, hipHostMallocDefault));
         for (int i = 0; i < 2; ++i) HAC_HIP(hipEventCreateWithFlags(&stage_ev[i], hipEventDisableTiming));
@@ -895,6 +900,13 @@ struct DeviceIndex {
             (void)hipEventDestroy(e.first);
             (void)hipEventDestroy(e.second);
         }
+        if (stream2) {
+            (void)hipStreamSynchronize(stream2);
+            (void)hipStreamDestroy(stream2);
+        }
+        for (int i = 0; i < 2; ++i)
+            if (ev_chunk[i]) (void)hipEventDestroy(ev_chunk[i]);
+        if (ev_tail) (void)hipEventDestroy(ev_tail);
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -1273,6 +1285,10 @@ struct DeviceIndex {
     // Cascade: one fp16 product per score (|s~ - s| ~ 1.2e-3 |q||x| proven) decides every query whose candidate
     // list it can certify; if many fail, three products (hi/lo split, ~2.8e-4 |q||x|, three times the MFMA work)
     // retry those; whatever is left goes to the exact fp32 kernels.  level 0 -> terms 1, level 1 -> terms 3.
+    //
+    // Queries go through in chunks of at most 1024 (four 256-query tiles x 64 row streams fill the chip): the
+    // rescoring of chunk c (HBM gathers, no matrix work) runs on a second stream under the scan of chunk c+1.
+    static constexpr int64_t SPLIT_CHUNK = 1024;
     int search_keys_split(const float *q_dev, int64_t nq, int k, u64 *keys_out, u32 pos_base, hipStream_t st, int level = 0) {
         const int K2 = SPLIT_K2, C2 = SPLIT_C2;
         int terms = level == 0 ? 1 : 3;
@@ -1281,35 +1297,26 @@ struct DeviceIndex {
         }
         HAC_TRY(upload_segs(st));
         const u32 G = (u32)((ntotal + GROUP_ROWS - 1) / GROUP_ROWS);
-        const int n_qtiles = (int)((nq + SH_NQ - 1) / SH_NQ);
-        const int64_t nq_pad = (int64_t)n_qtiles * SH_NQ;
-        long P = std::max<long>(1, n_cu / n_qtiles);
-        if (P >= 8) P = P / 8 * 8;  // same-row workgroups of different query tiles share an XCD (L2)
-        P = std::max<long>(1, std::min<long>(P, (G + SH_GPR - 1) / SH_GPR));
+        const int64_t chunk = std::min<int64_t>(nq, SPLIT_CHUNK);
+        const int n_qtiles_max = (int)((chunk + SH_NQ - 1) / SH_NQ);
         const size_t lds = terms == 3 ? ShCfg<3>::LDS : ShCfg<1>::LDS;
-        HAC_TRY(ws_qsplit.reserve((size_t)nq_pad * d * 2 * (terms == 3 ? 2 : 1)));
-        HAC_TRY(ws_delta.reserve((size_t)nq_pad * 4));
-        HAC_TRY(ws_cand.reserve((size_t)P * n_qtiles * SH_NQ * C2 * 8));
-        const long pstride = (long)P * K2;
-        HAC_TRY(ws_partial.reserve((size_t)nq * pstride * 8));
-        HAC_TRY(ws_pcnt.reserve((size_t)nq * 4));
-        HAC_TRY(ws_thrglob.reserve((size_t)nq_pad * 4));
+        long Pmax = std::max<long>(1, n_cu);
+        HAC_TRY(ws_qsplit.reserve((size_t)n_qtiles_max * SH_NQ * d * 2 * (terms == 3 ? 2 : 1)));
+        HAC_TRY(ws_delta.reserve((size_t)(nq + SH_NQ) * 4));
+        HAC_TRY(ws_cand.reserve((size_t)Pmax * SH_NQ * C2 * 8));          // P * n_qtiles <= n_cu workgroups
+        HAC_TRY(ws_partial.reserve((size_t)chunk * Pmax * K2 * 8));
+        HAC_TRY(ws_pcnt.reserve((size_t)chunk * 4));
+        HAC_TRY(ws_thrglob.reserve((size_t)n_qtiles_max * SH_NQ * 4));
         HAC_TRY(ws_akeys.reserve((size_t)nq * K2 * 8));
         HAC_TRY(ws_fail.reserve((size_t)nq * 4));
         HAC_TRY(ws_stat.reserve(16));
-        HAC_TRY(ws_thr.reserve((size_t)nq * 4));
+        HAC_TRY(ws_thr.reserve((size_t)chunk * 4));
         HAC_TRY(fb_reserve((size_t)nq + 8));
-
-        split_queries_kernel<<<dim3((unsigned)nq_pad), dim3(192), 0, st>>>(reinterpret_cast<const float4 *>(q_dev), (int)nq, K4, terms,
-                                                                          (const u32 *)ws_norm.p, (h16 *)ws_qsplit.p,
-                                                                          (float *)ws_delta.p);
-        HAC_HIP(hipGetLastError());
+        HAC_HIP(hipMemsetAsync(ws_stat.p, 0, 16, st));
 
         ScanArgs a{};
         a.segs = d_segs;
         a.nseg = nseg_live;
-        a.q = reinterpret_cast<const float4 *>(q_dev);
-        a.nq = (int)nq;
         a.K4 = K4;
         a.n_rows = (long)ntotal;
         a.pos_base = pos_base;
@@ -1321,62 +1328,88 @@ struct DeviceIndex {
         a.partial_cnt = (u32 *)ws_pcnt.p;
         SplitArgs sp{};
         sp.qsplit = (const u32x4 *)ws_qsplit.p;
-        sp.delta = (const float *)ws_delta.p;
         sp.cand = (u64 *)ws_cand.p;
         sp.C2 = C2;
         sp.K2 = K2;
-        sp.pstride = pstride;
         sp.thr_is_approx = 1;
-        HAC_HIP(hipMemsetAsync(ws_pcnt.p, 0, (size_t)nq * 4, st));
-        HAC_HIP(hipMemsetAsync(ws_thrglob.p, 0, (size_t)nq_pad * 4, st));
-        HAC_HIP(hipMemsetAsync(ws_stat.p, 0, 16, st));
-        if (profiling) {
-            if (ev_used == ev_pool.size()) {
-                hipEvent_t a0, a1;
-                HAC_HIP(hipEventCreate(&a0));
-                HAC_HIP(hipEventCreate(&a1));
-                ev_pool.emplace_back(a0, a1);
+        long P_last = 0;
+        int n_qtiles_last = 0, seeded = 0, n_chunks = 0;
+        for (int64_t off = 0; off < nq; off += chunk, ++n_chunks) {
+            const int64_t n = std::min<int64_t>(chunk, nq - off);
+            const float *qc = q_dev + (size_t)off * d;
+            const int n_qtiles = (int)((n + SH_NQ - 1) / SH_NQ);
+            const int64_t nq_pad = (int64_t)n_qtiles * SH_NQ;
+            long P = std::max<long>(1, n_cu / n_qtiles);
+            if (P >= 8) P = P / 8 * 8;  // same-row workgroups of different query tiles share an XCD (L2)
+            P = std::max<long>(1, std::min<long>(P, (G + SH_GPR - 1) / SH_GPR));
+            const long pstride = (long)P * K2;
+            float *delta_c = (float *)ws_delta.p + off;
+            u64 *akeys_c = (u64 *)ws_akeys.p + (size_t)off * K2;
+            split_queries_kernel<<<dim3((unsigned)nq_pad), dim3(192), 0, st>>>(reinterpret_cast<const float4 *>(qc), (int)n, K4, terms,
+                                                                              (const u32 *)ws_norm.p, (h16 *)ws_qsplit.p, delta_c);
+            HAC_HIP(hipGetLastError());
+            a.q = reinterpret_cast<const float4 *>(qc);
+            a.nq = (int)n;
+            sp.delta = delta_c;
+            sp.pstride = pstride;
+            HAC_HIP(hipMemsetAsync(ws_pcnt.p, 0, (size_t)n * 4, st));
+            HAC_HIP(hipMemsetAsync(ws_thrglob.p, 0, (size_t)nq_pad * 4, st));
+            if (profiling) {
+                if (ev_used == ev_pool.size()) {
+                    hipEvent_t a0, a1;
+                    HAC_HIP(hipEventCreate(&a0));
+                    HAC_HIP(hipEventCreate(&a1));
+                    ev_pool.emplace_back(a0, a1);
+                }
+                HAC_HIP(hipEventRecord(ev_pool[ev_used].first, st));
             }
-            HAC_HIP(hipEventRecord(ev_pool[ev_used].first, st));
-        }
-        // Seeding pass: the first sixteenth of the corpus (at least ~48k rows) is scored once just for its
-        // per-quarter maxima; their K2-th largest opens the real pass over ALL rows with thresholds that only
-        // ~K2 * 16 rows per query pass.  Without sharp opening thresholds list compactions (sorts) cost as
-        // much as half the MFMA work.
-        const dim3 grid((unsigned)P, (unsigned)n_qtiles), blk(SH_W * 64);
-        const u32 round_groups = (u32)P * SH_GPR;
-        u32 GA = std::min<u32>(G, (std::max<u32>(G / 16u, 768u) + round_groups - 1u) / round_groups * round_groups);
-        const float *thr_init = nullptr;
-        if ((size_t)4 * GA >= (size_t)K2) {
-            const u32 S = 4u * GA;
-            HAC_TRY(ws_seedkeys.reserve((size_t)nq * S * 4));
-            a.n_items = GA;
-            a.thr_init = nullptr;
-            sp.maxima = (float *)ws_seedkeys.p;
-            if (terms == 3) scanh_kernel<3, true><<<grid, blk, lds, st>>>(a, sp);
-            else scanh_kernel<1, true><<<grid, blk, lds, st>>>(a, sp);
+            // Seeding pass: the first sixteenth of the corpus (at least ~48k rows) is scored once just for its
+            // per-quarter maxima; their K2-th largest opens the real pass over ALL rows with thresholds that only
+            // ~K2 * 16 rows per query pass.  Without sharp opening thresholds list compactions (sorts) cost as
+            // much as half the MFMA work.
+            const dim3 grid((unsigned)P, (unsigned)n_qtiles), blk(SH_W * 64);
+            const u32 round_groups = (u32)P * SH_GPR;
+            u32 GA = std::min<u32>(G, (std::max<u32>(G / 16u, 768u) + round_groups - 1u) / round_groups * round_groups);
+            const float *thr_init = nullptr;
+            if ((size_t)4 * GA >= (size_t)K2) {
+                const u32 S = 4u * GA;
+                HAC_TRY(ws_seedkeys.reserve((size_t)chunk * S * 4));
+                a.n_items = GA;
+                a.thr_init = nullptr;
+                sp.maxima = (float *)ws_seedkeys.p;
+                if (terms == 3) scanh_kernel<3, true><<<grid, blk, lds, st>>>(a, sp);
+                else scanh_kernel<1, true><<<grid, blk, lds, st>>>(a, sp);
+                HAC_HIP(hipGetLastError());
+                kth_select_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>((const float *)ws_seedkeys.p, S, K2, (float *)ws_thr.p);
+                HAC_HIP(hipGetLastError());
+                thr_init = (const float *)ws_thr.p;
+            }
+            a.n_items = G;
+            a.thr_init = thr_init;
+            if (terms == 3) scanh_kernel<3, false><<<grid, blk, lds, st>>>(a, sp);
+            else scanh_kernel<1, false><<<grid, blk, lds, st>>>(a, sp);
             HAC_HIP(hipGetLastError());
-            kth_select_kernel<<<dim3((unsigned)nq), dim3(256), 0, st>>>((const float *)ws_seedkeys.p, S, K2, (float *)ws_thr.p);
+            if (profiling) {
+                HAC_HIP(hipEventRecord(ev_pool[ev_used].second, st));
+                ++ev_used;
+            }
+            // exact top-K2 by approximate score over all workgroups' survivors
+            select_keys_kernel<<<dim3((unsigned)n), dim3(256), (size_t)K2 * 8, st>>>((const u64 *)ws_partial.p, (size_t)pstride,
+                                                                                     (const u32 *)ws_pcnt.p, (u32)pstride, K2, K2, akeys_c, nullptr);
             HAC_HIP(hipGetLastError());
-            thr_init = (const float *)ws_thr.p;
+            // rescoring + certificate of this chunk on the second stream (reads only akeys, delta, the queries and
+            // the corpus; everything the next chunk's scan reuses is already consumed)
+            HAC_HIP(hipEventRecord(ev_chunk[n_chunks & 1], st));
+            HAC_HIP(hipStreamWaitEvent(stream2, ev_chunk[n_chunks & 1], 0));
+            rescore_kernel<<<dim3((unsigned)n), dim3(256), 0, stream2>>>(a, akeys_c, delta_c, K2, k, keys_out + (size_t)off * k,
+                                                                        (u32 *)ws_fail.p + off, (u32 *)ws_stat.p);
+            HAC_HIP(hipGetLastError());
+            P_last = P;
+            n_qtiles_last = n_qtiles;
+            seeded = thr_init ? 1 : 0;
         }
-        a.n_items = G;
-        a.thr_init = thr_init;
-        if (terms == 3) scanh_kernel<3, false><<<grid, blk, lds, st>>>(a, sp);
-        else scanh_kernel<1, false><<<grid, blk, lds, st>>>(a, sp);
-        HAC_HIP(hipGetLastError());
-        if (profiling) {
-            HAC_HIP(hipEventRecord(ev_pool[ev_used].second, st));
-            ++ev_used;
-        }
-        // exact top-K2 by approximate score over all workgroups' survivors
-        select_keys_kernel<<<dim3((unsigned)nq), dim3(256), (size_t)K2 * 8, st>>>((const u64 *)ws_partial.p, (size_t)pstride,
-                                                                                  (const u32 *)ws_pcnt.p, (u32)pstride, K2, K2,
-                                                                                  (u64 *)ws_akeys.p, nullptr);
-        HAC_HIP(hipGetLastError());
-        rescore_kernel<<<dim3((unsigned)nq), dim3(256), 0, st>>>(a, (const u64 *)ws_akeys.p, (const float *)ws_delta.p, K2, k, keys_out,
-                                                               (u32 *)ws_fail.p, (u32 *)ws_stat.p);
-        HAC_HIP(hipGetLastError());
+        HAC_HIP(hipEventRecord(ev_tail, stream2));
+        HAC_HIP(hipStreamWaitEvent(st, ev_tail, 0));
         HAC_HIP(hipMemcpyAsync(h_fb, ws_stat.p, 8, hipMemcpyDeviceToHost, st));
         HAC_HIP(hipStreamSynchronize(st));
         const u32 nfail = h_fb[0];
@@ -1384,8 +1417,8 @@ struct DeviceIndex {
         std::memcpy(&maxratio, &h_fb[1], 4);
         if (level == 0) ++split_searches;
         char plan_here[sizeof last_plan];
-        snprintf(plan_here, sizeof plan_here, "split: scanh_kernel<%d> grid=(%ld,%d) NQ=%d K2=%d lds=%zu seed=%d fallback=%u/%lld err/bound=%.3g",
-                 terms, P, n_qtiles, SH_NQ, K2, lds, thr_init ? 1 : 0, nfail, (long long)nq, (double)maxratio);
+        snprintf(plan_here, sizeof plan_here, "split: scanh_kernel<%d> grid=(%ld,%d) NQ=%d K2=%d chunks=%d lds=%zu seed=%d fallback=%u/%lld err/bound=%.3g",
+                 terms, P_last, n_qtiles_last, SH_NQ, K2, n_chunks, lds, seeded, nfail, (long long)nq, (double)maxratio);
         std::memcpy(last_plan, plan_here, sizeof last_plan);
         if (nfail == 0) return HAC_OK;
 
@@ -1408,13 +1441,12 @@ struct DeviceIndex {
         HAC_HIP(hipGetLastError());
         HAC_HIP(hipStreamSynchronize(st));   // h_fb is reused by the next level
         const bool prof = profiling;
-        profiling = false;   // one timed kernel per search: the first prefilter
+        profiling = false;   // timed kernels of a search: the first level's scans
         int rc;
         if (terms == 1 && nf >= 64) {
             rc = search_keys_split((const float *)fbq.p, nf, k, (u64 *)fbkeys.p, pos_base, st, 1);
-            // "a;b": the second level's line after the first's
             char both[sizeof last_plan];
-            snprintf(both, sizeof both, "%.150s ; then %.140s", plan_here, last_plan + 7);
+            snprintf(both, sizeof both, "%.160s ; then %.130s", plan_here, last_plan + 7);
             std::memcpy(plan_here, both, sizeof plan_here);
         } else {
             split_fallback_queries += nf;
@@ -1432,20 +1464,18 @@ struct DeviceIndex {
 
     // keys_out: device u64 [nq][k], canonical (score desc, row asc) keys of the k best rows per query.
     // Large query sets (the reference searches a whole test set per block: 2.5k - 16k queries) go through
-    // in chunks of 1024: four 256-query tiles x 64 row streams (or 16 x 16 for the exact kernels) fill the
-    // chip with same-row workgroups sharing an XCD; one launch over 33 query tiles does neither.
+    // in chunks: 512 inside the prefilter (search_keys_split), 1024 for the exact kernels (16 query tiles x 16
+    // row streams fill the chip with same-row workgroups sharing an XCD; one launch over 33 query tiles does neither).
     static constexpr int64_t QUERY_CHUNK = 1024;
     int search_keys(const float *q_dev, int64_t nq, int k, u64 *keys_out, u32 pos_base, hipStream_t st) {
         if (nq > 0 && ntotal > 0) {
             if (((uintptr_t)q_dev & 15) != 0) return fail(HAC_ERR_INVALID, "search: query pointer must be 16-byte aligned");
             if ((uint64_t)pos_base + (uint64_t)ntotal > 0xFFFFFFFFull) return fail(HAC_ERR_UNSUPPORTED, "row positions exceed 32 bits");
         }
+        if (nq > 0 && ntotal > 0 && split_eligible(nq, k)) return search_keys_split(q_dev, nq, k, keys_out, pos_base, st);
         for (int64_t off = 0; off < nq || off == 0; off += QUERY_CHUNK) {
             const int64_t n = std::min<int64_t>(QUERY_CHUNK, nq - off);
-            const float *qc = q_dev + (size_t)off * d;
-            u64 *kc = keys_out + (size_t)off * k;
-            if (n > 0 && ntotal > 0 && split_eligible(n, k)) HAC_TRY(search_keys_split(qc, n, k, kc, pos_base, st));
-            else HAC_TRY(search_keys_exact(qc, n, k, kc, pos_base, st));
+            HAC_TRY(search_keys_exact(q_dev + (size_t)off * d, n, k, keys_out + (size_t)off * k, pos_base, st));
             if (nq == 0) break;
         }
         return HAC_OK;
