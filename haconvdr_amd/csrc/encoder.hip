@@ -915,11 +915,13 @@ int to_bf16(hac_encoder *e, const float *src, size_t n, bf16 **out) {
     return HAC_OK;
 }
 
+// rows_hint: an upper bound of the packed rows of this sub-batch when the caller knows one (sum of its
+// sequences' padded lengths), 0 = every sequence may be full length
 template <typename IT>
-int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, float *out_dev, hipStream_t st) {
+int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, float *out_dev, hipStream_t st, long rows_hint = 0) {
     const hac_encoder_config &c = e->cfg;
     const int L32 = (L + SEQ_ALIGN - 1) / SEQ_ALIGN * SEQ_ALIGN;
-    const long rows_max = (long)B * L32;
+    const long rows_max = rows_hint > 0 ? std::min<long>(rows_hint, (long)B * L32) : (long)B * L32;
     const long Mp = (rows_max + MT - 1) / MT * MT;
     HAC_TRY(e->ws_x.reserve((size_t)Mp * H * 4));
     HAC_TRY(e->ws_y.reserve((size_t)Mp * H * 4));
@@ -1042,10 +1044,37 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
 template <typename IT>
 int forward_batched(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, float *out_dev, hipStream_t st) {
     const int L32 = (L + SEQ_ALIGN - 1) / SEQ_ALIGN * SEQ_ALIGN;
-    int per = (int)std::max<long>(1, e->max_tokens / L32);
-    for (int b0 = 0; b0 < B; b0 += per) {
-        const int nb = std::min(per, B - b0);
-        HAC_TRY(run_forward<IT>(e, ids + (size_t)b0 * L, mask + (size_t)b0 * L, nb, L, out_dev + (size_t)b0 * H, st));
+    if ((long)B * L32 <= e->max_tokens) return run_forward<IT>(e, ids, mask, B, L, out_dev, st);
+    // More rows than one pass holds if every sequence were full length: size the sub-batches by the REAL padded
+    // lengths (one seq_prep over the whole batch and a B-int read-back), so that varlen batches fill the
+    // max_tokens-row GEMMs instead of running them half empty.
+    const size_t seq_ints = (size_t)3 * B + 2 + 2 + (size_t)B * L;
+    HAC_TRY(e->ws_seq.reserve(seq_ints * 4));
+    SeqInfo s;
+    int *p = (int *)e->ws_seq.p;
+    s.lens = p;
+    s.len32 = p + B;
+    s.off = p + 2 * B;
+    s.err = p + 3 * B + 2;
+    s.nb = p + 3 * B + 3;
+    s.pos = p + 3 * B + 4;
+    HAC_HIP(hipMemsetAsync(s.err, 0, 4, st));
+    seq_prep_kernel<IT><<<dim3(B), dim3(512), 0, st>>>(ids, mask, L, s, e->cfg.pad_token_id);
+    HAC_HIP(hipGetLastError());
+    HAC_HIP(hipStreamSynchronize(st));
+    std::vector<int> len32((size_t)B);
+    HAC_HIP(hipMemcpy(len32.data(), s.len32, (size_t)B * 4, hipMemcpyDeviceToHost));
+    for (int b0 = 0; b0 < B;) {
+        long rows = 0;
+        int nb = 0;
+        while (b0 + nb < B) {
+            const long r = std::min<long>(std::max(len32[(size_t)b0 + nb], SEQ_ALIGN), L32);   // invalid masks are reported by the sub-batch itself
+            if (nb > 0 && rows + r > e->max_tokens) break;
+            rows += r;
+            ++nb;
+        }
+        HAC_TRY(run_forward<IT>(e, ids + (size_t)b0 * L, mask + (size_t)b0 * L, nb, L, out_dev + (size_t)b0 * H, st, rows));
+        b0 += nb;
     }
     return HAC_OK;
 }
