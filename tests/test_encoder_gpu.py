@@ -99,12 +99,20 @@ def test_large_batch_subbatching():
     """More rows than one sub-batch holds: same embeddings as the small batches."""
     from haconvdr_amd import synth
     enc = encoder(2)
-    ids, lens = synth.token_batch(31, 600, 384, min_len=8)
+    ids, lens = synth.token_batch(31, 1500, 384, min_len=8)      # 576k padded rows, ~300k real: two length-sized sub-batches
     mask = (np.arange(384)[None, :] < lens[:, None]).astype(np.int32)
     out = enc(ids, mask)
     assert np.isfinite(out).all()
-    sel = [0, 17, 599]
+    sel = [0, 17, 599, 1100, 1499]
     np.testing.assert_array_equal(out[sel], enc(ids[sel], mask[sel]))
+    full = np.ones((900, 384), np.int32)                          # every sequence full length: 345k rows, split by count
+    outf = enc(ids[:900], full)
+    np.testing.assert_array_equal(outf[[0, 450, 899]], enc(ids[[0, 450, 899]], full[:3]))
+    from haconvdr_amd._lib import HacError
+    bad = mask.copy()
+    bad[1400, 2] = 0                                              # a hole in a sequence of the LAST sub-batch
+    with pytest.raises(HacError):
+        enc(ids, bad)
 
 
 def test_bad_masks_fail_loudly():
