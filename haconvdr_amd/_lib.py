@@ -38,6 +38,7 @@ def _declare(L):
     L.hac_index_reset.argtypes = [vp]
     L.hac_index_ntotal.argtypes = [vp]
     L.hac_index_ntotal.restype = i64
+    L.hac_index_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p]
     L.hac_index_set_profiling.argtypes = [vp, ctypes.c_int]
     L.hac_index_profile_drain.argtypes = [vp, c_f32p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
     L.hac_index_last_plan.argtypes = [vp]
@@ -53,12 +54,14 @@ def _declare(L):
     L.hac_encoder_forward_device.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]
     L.hac_encoder_set_profiling.argtypes = [vp, ctypes.c_int]
     L.hac_encoder_profile_drain.argtypes = [vp, c_f32p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    L.hac_encoder_profile_drain_class.argtypes = [vp, ctypes.c_int, c_f32p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
     for name in ("hac_encoder_create", "hac_encoder_set_weight", "hac_encoder_finalize", "hac_encoder_forward",
-                 "hac_encoder_forward_device", "hac_encoder_set_profiling", "hac_encoder_profile_drain"):
+                 "hac_encoder_forward_device", "hac_encoder_set_profiling", "hac_encoder_profile_drain",
+                 "hac_encoder_profile_drain_class"):
         getattr(L, name).restype = ctypes.c_int
     for name in ("hac_index_create", "hac_index_add", "hac_index_add_device", "hac_index_search",
                  "hac_index_search_device", "hac_index_search_keys_device", "hac_index_reset",
-                 "hac_index_set_profiling", "hac_index_profile_drain", "hac_merge_keys_device",
+                 "hac_index_set_option", "hac_index_set_profiling", "hac_index_profile_drain", "hac_merge_keys_device",
                  "hac_keys_to_results_device"):
         getattr(L, name).restype = ctypes.c_int
 
@@ -67,10 +70,10 @@ def _declare(L):
 EXPORTED_SYMBOLS = (
     "hac_last_error", "hac_version", "hac_index_create", "hac_index_destroy", "hac_index_add",
     "hac_index_add_device", "hac_index_search", "hac_index_search_device", "hac_index_search_keys_device",
-    "hac_index_reset", "hac_index_ntotal", "hac_index_set_profiling", "hac_index_profile_drain", "hac_index_last_plan",
+    "hac_index_reset", "hac_index_ntotal", "hac_index_set_option", "hac_index_set_profiling", "hac_index_profile_drain", "hac_index_last_plan",
     "hac_merge_keys_device", "hac_keys_to_results_device",
     "hac_encoder_create", "hac_encoder_destroy", "hac_encoder_set_weight", "hac_encoder_finalize", "hac_encoder_forward",
-    "hac_encoder_forward_device", "hac_encoder_set_profiling", "hac_encoder_profile_drain",
+    "hac_encoder_forward_device", "hac_encoder_set_profiling", "hac_encoder_profile_drain", "hac_encoder_profile_drain_class",
 )
 
 

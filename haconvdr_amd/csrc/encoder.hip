@@ -59,7 +59,7 @@ struct SeqInfo {
     int *len32;   // [B] rows occupied (multiple of 32)
     int *off;     // [B+1] first packed row of each sequence; off[B] = total rows
     int *pos;     // [B][L] position ids (HF rule), valid for t < len
-    int *err;     // [1] != 0 if some mask is not a prefix mask / empty
+    int *err;     // [B] per sequence: 1 mask is not a prefix mask, 2 mask is empty, 4 a token id outside [0, vocab)
     int *nb;      // [1] number of sequences (device copy; row count of the CLS-only tail)
 };
 
@@ -67,15 +67,19 @@ struct SeqInfo {
 //   pos = cumsum(id != pad) * (id != pad) + pad     (pad = 1)
 template <typename IT>
 __global__ __launch_bounds__(512) void seq_prep_kernel(const IT *__restrict__ ids, const IT *__restrict__ mask, int L, SeqInfo s,
-                                                       int pad_id) {
+                                                       int pad_id, int vocab) {
     __shared__ int wsum[8];
     __shared__ int wlen[8];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int t = tid;
     int m = 0, np = 0;
+    bool id_ok = true;
+    if (tid == 0) s.err[b] = 0;
     if (t < L) {
         m = mask[(size_t)b * L + t] != 0;
-        np = ids[(size_t)b * L + t] != (IT)pad_id;
+        const IT id = ids[(size_t)b * L + t];
+        np = id != (IT)pad_id;
+        id_ok = id >= (IT)0 && id < (IT)vocab;   // nn.Embedding raises on such an id; here the sequence is flagged (NaN row)
     }
     // block reductions / scans over 512 threads (8 waves)
     int mlen = m;
@@ -98,10 +102,11 @@ __global__ __launch_bounds__(512) void seq_prep_kernel(const IT *__restrict__ id
     const int cum = sc + base;
     if (t < L) {
         s.pos[(size_t)b * L + t] = np ? cum + pad_id : pad_id;
-        if ((m != 0) != (t < len)) atomicOr(s.err, 1);  // not a prefix mask
+        if ((m != 0) != (t < len)) atomicOr(s.err + b, 1);  // not a prefix mask
+        if (t < len && !id_ok) atomicOr(s.err + b, 4);      // only attended tokens are looked up
     }
     if (tid == 0) {
-        if (len <= 0) atomicOr(s.err, 2);
+        if (len <= 0) atomicOr(s.err + b, 2);
         s.lens[b] = len;
         s.len32[b] = (len + SEQ_ALIGN - 1) / SEQ_ALIGN * SEQ_ALIGN;
     }
@@ -161,7 +166,7 @@ template <typename IT>
 __global__ __launch_bounds__(256) void embed_ln_kernel(const IT *__restrict__ ids, int L, SeqInfo s, const float *__restrict__ word,
                                                        const float *__restrict__ posw, const float *__restrict__ typew,
                                                        const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
-                                                       float *__restrict__ x_f32, bf16 *__restrict__ x_bf) {
+                                                       int vocab, float *__restrict__ x_f32, bf16 *__restrict__ x_bf) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int b = blockIdx.y;
@@ -169,7 +174,8 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const IT *__restrict__ id
     const size_t row = (size_t)s.off[b] + t;
     float v[12];
     if (t < s.lens[b]) {
-        const long id = (long)ids[(size_t)b * L + t];
+        long id = (long)ids[(size_t)b * L + t];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);   // out-of-range ids were flagged by seq_prep_kernel; never read outside the table
         const int p = s.pos[(size_t)b * L + t];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -818,7 +824,7 @@ __global__ __launch_bounds__(256) void cls_head_kernel(const float *__restrict__
     const float *xr = x + (size_t)(compact ? b : s.off[b]) * H;
     for (int i = tid; i < H; i += 256) xs[i] = xr[i];
     __syncthreads();
-    const bool bad = *s.err != 0;
+    const bool bad = s.err[b] != 0;
     // each wave computes 192 outputs; a wave reads one weight row at a time (coalesced) and reduces
     for (int n = w; n < H; n += 4) {
         const float *wr = Wh + (size_t)n * H;
@@ -847,7 +853,7 @@ __global__ __launch_bounds__(256) void cls_head_kernel(const float *__restrict__
     const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) * (1.0f / H) + eps);
     for (int i = tid; i < H; i += 256) {
         const float v = (es[i] - mean) * rstd * gamma[i] + beta[i];
-        out[(size_t)b * H + i] = bad ? NAN : v;  // unsupported (non-prefix / empty) mask: fail loudly, never guess
+        out[(size_t)b * H + i] = bad ? NAN : v;  // unsupported mask or token id of THIS sequence: fail loudly, never guess
     }
 }
 
@@ -888,10 +894,15 @@ struct hac_encoder {
     GrowBuf ws_x, ws_xb, ws_q, ws_k, ws_vt, ws_ctx, ws_y, ws_h, ws_seq, ws_ids, ws_mask, ws_out, ws_cls, ws_stats;
     void *h_pin = nullptr;
     size_t h_pin_bytes = 0;
-    // profiling (bench): events around the layer stack of each forward
-    bool profiling = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
-    size_t ev_used = 0;
+    int *h_len = nullptr;      // pinned: padded lengths of a forward that runs as several sub-batches
+    size_t h_len_cap = 0;
+    // profiling (bench): hipEvent pairs on the launch stream.  Bit 0 of prof_mask: around the layer stack of each
+    // forward (pool 0); bit 1+c: around every launch of kernel class c (pool 1+c), see HAC_ENC_CLASS_* in the header.
+    unsigned prof_mask = 0;
+    struct EvPool {
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+        size_t used = 0;
+    } pools[1 + HAC_ENC_NCLASS];
     long max_tokens = 262144;  // packed rows per sub-batch (workspaces: ~4.5 GB; 131072 is 2 % slower, 524288 no faster)
     int n_cu = 256;
 };
@@ -915,6 +926,40 @@ int to_bf16(hac_encoder *e, const float *src, size_t n, bf16 **out) {
     return HAC_OK;
 }
 
+int prof_begin(hac_encoder *e, int pool, hipStream_t st) {
+    if (!((e->prof_mask >> pool) & 1u)) return HAC_OK;
+    auto &pl = e->pools[pool];
+    if (pl.used == pl.ev.size()) {
+        hipEvent_t a0, a1;
+        HAC_HIP(hipEventCreate(&a0));
+        HAC_HIP(hipEventCreate(&a1));
+        pl.ev.emplace_back(a0, a1);
+    }
+    HAC_HIP(hipEventRecord(pl.ev[pl.used].first, st));
+    return HAC_OK;
+}
+int prof_end(hac_encoder *e, int pool, hipStream_t st) {
+    if (!((e->prof_mask >> pool) & 1u)) return HAC_OK;
+    auto &pl = e->pools[pool];
+    HAC_HIP(hipEventRecord(pl.ev[pl.used].second, st));
+    ++pl.used;
+    return HAC_OK;
+}
+
+// carve the sequence bookkeeping of a (sub-)batch out of ws_seq
+int seq_layout(hac_encoder *e, int B, int L, SeqInfo &s) {
+    const size_t seq_ints = (size_t)4 * B + 4 + (size_t)B * L;
+    HAC_TRY(e->ws_seq.reserve(seq_ints * 4));
+    int *p = (int *)e->ws_seq.p;
+    s.lens = p;
+    s.len32 = p + B;
+    s.off = p + 2 * B;          // B+1 entries
+    s.nb = p + 3 * B + 2;
+    s.err = p + 3 * B + 4;      // B entries
+    s.pos = p + 4 * B + 4;
+    return HAC_OK;
+}
+
 // rows_hint: an upper bound of the packed rows of this sub-batch when the caller knows one (sum of its
 // sequences' padded lengths), 0 = every sequence may be full length
 template <typename IT>
@@ -932,24 +977,15 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
     HAC_TRY(e->ws_vt.reserve((size_t)H * Mp * 2));
     HAC_TRY(e->ws_ctx.reserve((size_t)Mp * H * 2));
     HAC_TRY(e->ws_h.reserve((size_t)Mp * FF * 2));
-    const size_t seq_ints = (size_t)3 * B + 2 + 2 + (size_t)B * L;
-    HAC_TRY(e->ws_seq.reserve(seq_ints * 4));
     SeqInfo s;
-    int *p = (int *)e->ws_seq.p;
-    s.lens = p;
-    s.len32 = p + B;
-    s.off = p + 2 * B;          // B+1 entries
-    s.err = p + 3 * B + 2;
-    s.nb = p + 3 * B + 3;
-    s.pos = p + 3 * B + 4;
-    HAC_HIP(hipMemsetAsync(s.err, 0, 4, st));
-    seq_prep_kernel<IT><<<dim3(B), dim3(512), 0, st>>>(ids, mask, L, s, c.pad_token_id);
+    HAC_TRY(seq_layout(e, B, L, s));
+    seq_prep_kernel<IT><<<dim3(B), dim3(512), 0, st>>>(ids, mask, L, s, c.pad_token_id, c.vocab);
     seq_offsets_kernel<<<dim3(1), dim3(64), 0, st>>>(s, B);
     float *x = (float *)e->ws_x.p, *y = (float *)e->ws_y.p;
     float2 *statsA = (float2 *)e->ws_stats.p, *statsF = statsA + Mp;
     bf16 *xb = (bf16 *)e->ws_xb.p, *q = (bf16 *)e->ws_q.p, *k = (bf16 *)e->ws_k.p, *vt = (bf16 *)e->ws_vt.p;
     bf16 *ctx = (bf16 *)e->ws_ctx.p, *h = (bf16 *)e->ws_h.p;
-    embed_ln_kernel<IT><<<dim3(L32 / 4, B), dim3(256), 0, st>>>(ids, L, s, e->word, e->posw, e->typew, e->embg, e->embb, c.ln_eps, x, xb);
+    embed_ln_kernel<IT><<<dim3(L32 / 4, B), dim3(256), 0, st>>>(ids, L, s, e->word, e->posw, e->typew, e->embg, e->embb, c.ln_eps, c.vocab, x, xb);
     HAC_HIP(hipGetLastError());
     const int *total = s.off + B;
     // dead tail rows of the last M tile (fewer than MT) feed the GEMMs: keep them finite
@@ -961,20 +997,14 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
     const size_t lds = (size_t)4 * bt * 128 + (size_t)(big ? 8 : 4) * 4096;   // 2 stages + per-wave patches
     const dim3 blk(big ? 512 : 256);
     const unsigned n_wg = (unsigned)(e->n_cu * (big ? 1 : 2));
-#define HAC_GEMM(EPI, NN)                                                             \
+#define HAC_GEMM(EPI, CLS)                                                            \
     do {                                                                              \
+        HAC_TRY(prof_begin(e, 1 + (CLS), st));                                        \
         if (big) gemm_bf16_nt_kernel<EPI, 4><<<dim3(n_wg), blk, lds, st>>>(g);         \
         else gemm_bf16_nt_kernel<EPI, 2><<<dim3(n_wg), blk, lds, st>>>(g);             \
+        HAC_TRY(prof_end(e, 1 + (CLS), st));                                          \
     } while (0)
-    if (e->profiling) {
-        if (e->ev_used == e->ev_pool.size()) {
-            hipEvent_t a0, a1;
-            HAC_HIP(hipEventCreate(&a0));
-            HAC_HIP(hipEventCreate(&a1));
-            e->ev_pool.emplace_back(a0, a1);
-        }
-        HAC_HIP(hipEventRecord(e->ev_pool[e->ev_used].first, st));
-    }
+    HAC_TRY(prof_begin(e, 0, st));
     // compact buffers of the CLS-only tail of the last layer
     const long Mc = ((long)B + MT - 1) / MT * MT;
     HAC_TRY(e->ws_cls.reserve((size_t)Mc * (H * 2 + H * 4 * 3 + H * 2 + FF * 2)));
@@ -991,11 +1021,13 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
         g.total_rows = total;
         // QKV
         g.A = xb; g.W = w.wqkv; g.bias = w.bqkv; g.N = 3 * H; g.K = H; g.q = q; g.k = k; g.v16 = vt;
-        HAC_GEMM(EPI_QKV, 3 * H);
+        HAC_GEMM(EPI_QKV, HAC_ENC_CLASS_QKV);
         AttnArgs a{q, k, vt, ctx, s, last ? 1 : 0};
         // sequences of <= 256 rows: 4-wave workgroups; longer ones: 8-wave workgroups (each skips the other's)
+        HAC_TRY(prof_begin(e, 1 + HAC_ENC_CLASS_ATTN, st));
         attention_kernel<4><<<dim3(NH, B), dim3(256), (size_t)(L32 < 256 ? L32 : 256) * 256, st>>>(a);
         if (L32 > 256) attention_kernel<8><<<dim3(NH, B), dim3(512), (size_t)L32 * 256, st>>>(a);
+        HAC_TRY(prof_end(e, 1 + HAC_ENC_CLASS_ATTN, st));
         // Residual stream between layers: layer 0 reads the embedding rows x (normalized); afterwards the
         // stream lives as pre-LayerNorm rows + (mean, rstd): yF/statsF after a layer's FFN, yA/statsA after its
         // attention block.  yF shares x's buffer (x is dead once layer 0's out-projection has read it).
@@ -1005,15 +1037,19 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
             // attention output projection + residual, LN statistics
             g.A = ctx; g.W = w.wo; g.bias = w.bo; g.N = H; g.K = H; g.resid = x; g.y = y;
             g.rstats = defer_in ? statsF : nullptr; g.rgamma = ln2g_prev; g.rbeta = ln2b_prev;
-            HAC_GEMM(EPI_RESID, H);
+            HAC_GEMM(EPI_RESID, HAC_ENC_CLASS_OUTPROJ);
+            HAC_TRY(prof_begin(e, 1 + HAC_ENC_CLASS_LN, st));
             ln_stats_rows_kernel<<<dim3((unsigned)(Mp / 4)), dim3(256), 0, st>>>(y, total, w.ln1g, w.ln1b, c.ln_eps, statsA, xb);
+            HAC_TRY(prof_end(e, 1 + HAC_ENC_CLASS_LN, st));
             // FFN
             g.A = xb; g.W = w.w1; g.bias = w.b1; g.N = FF; g.K = H; g.h = h;
-            HAC_GEMM(EPI_GELU, FF);
+            HAC_GEMM(EPI_GELU, HAC_ENC_CLASS_FFN_UP);
             g.A = h; g.W = w.w2; g.bias = w.b2; g.N = H; g.K = FF; g.resid = y; g.y = x;
             g.rstats = statsA; g.rgamma = w.ln1g; g.rbeta = w.ln1b;
-            HAC_GEMM(EPI_RESID, H);
+            HAC_GEMM(EPI_RESID, HAC_ENC_CLASS_FFN_DOWN);
+            HAC_TRY(prof_begin(e, 1 + HAC_ENC_CLASS_LN, st));
             ln_stats_rows_kernel<<<dim3((unsigned)(Mp / 4)), dim3(256), 0, st>>>(x, total, w.ln2g, w.ln2b, c.ln_eps, statsF, xb);
+            HAC_TRY(prof_end(e, 1 + HAC_ENC_CLASS_LN, st));
         } else {
             // only the <s> row of every sequence continues (B rows instead of T): same kernels, compact matrices
             gather_cls_kernel<<<dim3((unsigned)Mc), dim3(256), 0, st>>>(ctx, x, defer_in ? statsF : nullptr, ln2g_prev, ln2b_prev, s, B, ctx_c, x_c);
@@ -1032,10 +1068,7 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
         HAC_HIP(hipGetLastError());
     }
 #undef HAC_GEMM
-    if (e->profiling) {
-        HAC_HIP(hipEventRecord(e->ev_pool[e->ev_used].second, st));
-        ++e->ev_used;
-    }
+    HAC_TRY(prof_end(e, 0, st));
     cls_head_kernel<<<dim3(B), dim3(256), 0, st>>>(x_c, s, 1, e->wh, e->bh, e->ng, e->nb, 1e-5f, out_dev);
     HAC_HIP(hipGetLastError());
     return HAC_OK;
@@ -1048,22 +1081,22 @@ int forward_batched(hac_encoder *e, const IT *ids, const IT *mask, int B, int L,
     // More rows than one pass holds if every sequence were full length: size the sub-batches by the REAL padded
     // lengths (one seq_prep over the whole batch and a B-int read-back), so that varlen batches fill the
     // max_tokens-row GEMMs instead of running them half empty.
-    const size_t seq_ints = (size_t)3 * B + 2 + 2 + (size_t)B * L;
-    HAC_TRY(e->ws_seq.reserve(seq_ints * 4));
     SeqInfo s;
-    int *p = (int *)e->ws_seq.p;
-    s.lens = p;
-    s.len32 = p + B;
-    s.off = p + 2 * B;
-    s.err = p + 3 * B + 2;
-    s.nb = p + 3 * B + 3;
-    s.pos = p + 3 * B + 4;
-    HAC_HIP(hipMemsetAsync(s.err, 0, 4, st));
-    seq_prep_kernel<IT><<<dim3(B), dim3(512), 0, st>>>(ids, mask, L, s, e->cfg.pad_token_id);
+    HAC_TRY(seq_layout(e, B, L, s));
+    seq_prep_kernel<IT><<<dim3(B), dim3(512), 0, st>>>(ids, mask, L, s, e->cfg.pad_token_id, e->cfg.vocab);
     HAC_HIP(hipGetLastError());
+    // the one host read-back of a large forward: B ints through pinned memory, on the caller's stream
+    if (e->h_len_cap < (size_t)B) {
+        if (e->h_len) (void)hipHostFree(e->h_len);
+        e->h_len = nullptr;
+        e->h_len_cap = 0;
+        hipError_t err = hipHostMalloc((void **)&e->h_len, (size_t)B * 4 * 2, hipHostMallocDefault);
+        if (err != hipSuccess) return fail(HAC_ERR_OOM, "hipHostMalloc failed: %s", hipGetErrorString(err));
+        e->h_len_cap = (size_t)B * 2;
+    }
+    HAC_HIP(hipMemcpyAsync(e->h_len, s.len32, (size_t)B * 4, hipMemcpyDeviceToHost, st));
     HAC_HIP(hipStreamSynchronize(st));
-    std::vector<int> len32((size_t)B);
-    HAC_HIP(hipMemcpy(len32.data(), s.len32, (size_t)B * 4, hipMemcpyDeviceToHost));
+    const int *len32 = e->h_len;
     for (int b0 = 0; b0 < B;) {
         long rows = 0;
         int nb = 0;
@@ -1132,10 +1165,12 @@ void hac_encoder_destroy(hac_encoder *e) {
     for (GrowBuf *b : {&e->ws_x, &e->ws_xb, &e->ws_q, &e->ws_k, &e->ws_vt, &e->ws_ctx, &e->ws_y, &e->ws_h, &e->ws_seq, &e->ws_ids, &e->ws_mask, &e->ws_out, &e->ws_cls, &e->ws_stats})
         b->release();
     if (e->h_pin) (void)hipHostFree(e->h_pin);
-    for (auto &ev : e->ev_pool) {
-        (void)hipEventDestroy(ev.first);
-        (void)hipEventDestroy(ev.second);
-    }
+    if (e->h_len) (void)hipHostFree(e->h_len);
+    for (auto &pl : e->pools)
+        for (auto &ev : pl.ev) {
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -1258,27 +1293,40 @@ int hac_encoder_forward(hac_encoder *e, const int32_t *ids, const int32_t *mask,
     HAC_HIP(hipStreamSynchronize(e->stream));
     std::memcpy(out, e->h_pin, (size_t)B * H * 4);
     for (size_t i = 0; i < (size_t)B * H; ++i)
-        if (out[i] != out[i]) return fail(HAC_ERR_INVALID, "forward: attention_mask must be a non-empty prefix mask (first len ones) for every sequence");
+        if (out[i] != out[i])
+            return fail(HAC_ERR_INVALID, "forward: sequence %zu: attention_mask must be a non-empty prefix mask (first len ones) and attended token ids "
+                                         "must lie in [0, %d)", i / H, e->cfg.vocab);
     return HAC_OK;
 }
 
-int hac_encoder_set_profiling(hac_encoder *e, int enable) {
+int hac_encoder_set_profiling(hac_encoder *e, int mask) {
     if (!e) return fail(HAC_ERR_INVALID, "null encoder");
-    e->profiling = enable != 0;
+    e->prof_mask = (unsigned)mask & ((2u << HAC_ENC_NCLASS) - 1u);
+    return HAC_OK;
+}
+
+static int drain_pool(hac_encoder *e, int pool, float *ms_out, int cap, int *n_out) {
+    auto &pl = e->pools[pool];
+    int n = 0;
+    for (size_t i = 0; i < pl.used && n < cap; ++i, ++n) {
+        HAC_HIP(hipEventSynchronize(pl.ev[i].second));
+        HAC_HIP(hipEventElapsedTime(&ms_out[n], pl.ev[i].first, pl.ev[i].second));
+    }
+    pl.used = 0;
+    *n_out = n;
     return HAC_OK;
 }
 
 int hac_encoder_profile_drain(hac_encoder *e, float *ms_out, int cap, int *n_out) {
     if (!e || !n_out || (cap > 0 && !ms_out)) return fail(HAC_ERR_INVALID, "bad arguments");
     DeviceGuard g(e->device);
-    int n = 0;
-    for (size_t i = 0; i < e->ev_used && n < cap; ++i, ++n) {
-        HAC_HIP(hipEventSynchronize(e->ev_pool[i].second));
-        HAC_HIP(hipEventElapsedTime(&ms_out[n], e->ev_pool[i].first, e->ev_pool[i].second));
-    }
-    e->ev_used = 0;
-    *n_out = n;
-    return HAC_OK;
+    return drain_pool(e, 0, ms_out, cap, n_out);
+}
+
+int hac_encoder_profile_drain_class(hac_encoder *e, int cls, float *ms_out, int cap, int *n_out) {
+    if (!e || !n_out || (cap > 0 && !ms_out) || cls < 0 || cls >= HAC_ENC_NCLASS) return fail(HAC_ERR_INVALID, "bad arguments");
+    DeviceGuard g(e->device);
+    return drain_pool(e, 1 + cls, ms_out, cap, n_out);
 }
 
 }  // extern "C"

@@ -787,6 +787,29 @@ __global__ void keys_to_results_kernel(const u64 *__restrict__ keys, long n, con
     }
 }
 
+// In-process multi-device index: a shard numbers its rows densely in the order it received them, while the
+// contract numbers rows by insertion order over the WHOLE index (every add() is split across the shards).
+// spans[i] = (first shard-local row, rows, first global row) of the shard's share of add() number i; both
+// numberings grow with i, so the translation keeps a sorted key list sorted.
+struct SpanDesc {
+    u32 local0, count, global0, pad;
+};
+__global__ void remap_positions_kernel(u64 *__restrict__ keys, long n, const SpanDesc *__restrict__ spans, int n_spans) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 key = keys[i];
+    if (key == 0ull) return;
+    const u32 pos = 0xFFFFFFFFu - (u32)key;
+    int lo = 0, hi = n_spans - 1;   // last span with local0 <= pos
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (spans[mid].local0 <= pos) lo = mid;
+        else hi = mid - 1;
+    }
+    const u32 g = spans[lo].global0 + (pos - spans[lo].local0);
+    keys[i] = (key & 0xFFFFFFFF00000000ull) | (u64)(0xFFFFFFFFu - g);
+}
+
 u32 next_pow2(u32 v) {
     u32 p = 1;
     while (p < v) p <<= 1;
@@ -811,6 +834,35 @@ struct DeviceIndex {
     int64_t ntotal = 0;
     SegDesc *d_segs = nullptr;
     bool segs_dirty = true;
+    // Tuning / test switches.  The HAC_* environment variables are read ONCE, when the index is created, as the
+    // defaults; hac_index_set_option() changes them on a live handle (tests, bench).
+    struct Tuning {
+        int split = -1;          // prefilter: -1 by size, 0 never, 1 whenever the shape allows
+        int split_terms = 1;     // fp16 products per score at the first cascade level (1 or 3)
+        bool force_scan16 = false;
+        int scanq_nt = 0;        // 0: chosen by padding; 1..4 pins the query tiles per workgroup
+        int scanq_waves = 8;
+        bool no_p8 = false;
+    } tune;
+    void read_env() {
+        if (const char *e = getenv("HAC_SPLIT")) tune.split = e[0] == '0' ? 0 : (e[0] == '1' ? 1 : -1);
+        if (const char *e = getenv("HAC_SPLIT_TERMS")) tune.split_terms = e[0] == '3' ? 3 : 1;
+        if (const char *e = getenv("HAC_FORCE_SCAN16")) tune.force_scan16 = e[0] == '1';
+        if (const char *e = getenv("HAC_SCANQ_NT")) tune.scanq_nt = atoi(e);
+        if (const char *e = getenv("HAC_SCANQ_WAVES")) tune.scanq_waves = e[0] == '4' ? 4 : 8;
+        if (getenv("HAC_SCAN_NO_P8")) tune.no_p8 = true;
+    }
+    int set_option(const char *name, const char *value) {
+        const std::string n(name), v(value ? value : "");
+        if (n == "split") tune.split = v == "0" ? 0 : (v == "1" ? 1 : -1);
+        else if (n == "split_terms") tune.split_terms = v == "3" ? 3 : 1;
+        else if (n == "force_scan16") tune.force_scan16 = v == "1";
+        else if (n == "scanq_nt") tune.scanq_nt = atoi(v.c_str());
+        else if (n == "scanq_waves") tune.scanq_waves = v == "4" ? 4 : 8;
+        else if (n == "scan_no_p8") tune.no_p8 = v == "1";
+        else return fail(HAC_ERR_INVALID, "unknown index option '%s'", name);
+        return HAC_OK;
+    }
     GrowBuf ws_partial, ws_pcnt, ws_seedkeys, ws_thr, ws_thrglob, ws_q, ws_qt, ws_keys, ws_D, ws_I, ws_stage[2];
     // split-bf16 prefilter path (scan_split.inc)
     GrowBuf ws_norm, ws_qsplit, ws_delta, ws_cand, ws_akeys, ws_fail, ws_stat;
@@ -845,6 +897,7 @@ struct DeviceIndex {
         d = d_;
         K4 = d / 4;
         device = device_;
+        read_env();
         DeviceGuard g(device);
         if (!g.ok) return fail(HAC_ERR_HIP, "cannot select HIP device %d (no MI355X visible?)", device);
         hipDeviceProp_t prop;
@@ -1081,8 +1134,7 @@ struct DeviceIndex {
         pl.NT = 0;
         pl.W = SCAN_WAVES;
         // many queries: GEMM-shaped kernel, NQ = 32*NT queries per workgroup
-        const char *force = getenv("HAC_FORCE_SCAN16");
-        if (nq > 16 && K4 % 16 == 0 && !want16 && !(force && force[0] == '1')) {
+        if (nq > 16 && K4 % 16 == 0 && !want16 && !tune.force_scan16) {
             const int C2 = (int)std::max<u32>(32u, next_pow2((u32)k + 1u));
             int best_nt = 0;
             int64_t best_pad = 0;
@@ -1094,15 +1146,12 @@ struct DeviceIndex {
                     best_pad = pad;
                 }
             }
-            if (const char *fn = getenv("HAC_SCANQ_NT")) {   // tuning experiments only
-                const int nt = atoi(fn);
-                if (nt >= 1 && nt <= 4 && scanq_lds(32 * nt, C2) <= LDS_LIMIT) best_nt = nt;
-            }
+            if (tune.scanq_nt >= 1 && tune.scanq_nt <= 4 && scanq_lds(32 * tune.scanq_nt, C2) <= LDS_LIMIT)
+                best_nt = tune.scanq_nt;   // tuning experiments only
             if (best_nt) {
                 pl.kind = 1;
                 pl.NT = best_nt;
-                const char *we = getenv("HAC_SCANQ_WAVES");
-                pl.W = (we && we[0] == '4') ? 4 : 8;
+                pl.W = tune.scanq_waves;
                 pl.QT = 32 * best_nt;
                 pl.C = C2;
                 pl.lds_scan = scanq_lds(pl.QT, C2);
@@ -1124,7 +1173,7 @@ struct DeviceIndex {
         per_cu = std::max(1, std::min(per_cu, pl.kind == 1 ? 2 : 4));
         const long resident = (long)n_cu * per_cu;
         long P = std::max<long>(1, resident / pl.n_qtiles);
-        if (P >= 8 && !getenv("HAC_SCAN_NO_P8")) P = P / 8 * 8;  // same-row workgroups of different query tiles share an XCD (L2)
+        if (P >= 8 && !tune.no_p8) P = P / 8 * 8;  // same-row workgroups of different query tiles share an XCD (L2)
         const long maxP = (n_items + pl.W - 1) / pl.W;
         P = std::max<long>(1, std::min(P, maxP));
         pl.P = (int)P;
@@ -1262,12 +1311,11 @@ struct DeviceIndex {
     // exact kernels are bound by the fp32 matrix rate.  Worth its fixed cost only for many (query, row) pairs.
     static constexpr int SPLIT_K2 = 256, SPLIT_C2 = 512;
     bool split_eligible(int64_t nq, int k) const {
-        const char *e = getenv("HAC_SPLIT");   // "0": never, "1": whenever supported (tests), unset: by size
-        if (e && e[0] == '0') return false;
+        if (tune.split == 0) return false;   // 0: never, 1: whenever supported (tests), -1: by size
         // d % 64 == 0 (whole query slices) and at least 8 k-steps per row: the corpus ring runs 6 steps ahead and
         // may reach into the NEXT group only
         if (K4 % 16 != 0 || K4 < 32 || d > HAC_MAX_D || k > SPLIT_K2 - 64 || ntotal < SPLIT_K2) return false;
-        if (e && e[0] == '1') return true;
+        if (tune.split == 1) return true;
         return nq >= 48 && (double)nq * (double)ntotal >= 1.0e8;
     }
 
@@ -1291,10 +1339,7 @@ struct DeviceIndex {
     static constexpr int64_t SPLIT_CHUNK = 1024;
     int search_keys_split(const float *q_dev, int64_t nq, int k, u64 *keys_out, u32 pos_base, hipStream_t st, int level = 0) {
         const int K2 = SPLIT_K2, C2 = SPLIT_C2;
-        int terms = level == 0 ? 1 : 3;
-        if (const char *e = getenv("HAC_SPLIT_TERMS")) {   // tests: pin the first level
-            if (level == 0 && e[0] == '3') terms = 3;
-        }
+        const int terms = level == 0 ? tune.split_terms : 3;   // split_terms = 3: tests pin the first level
         HAC_TRY(upload_segs(st));
         const u32 G = (u32)((ntotal + GROUP_ROWS - 1) / GROUP_ROWS);
         const int64_t chunk = std::min<int64_t>(nq, SPLIT_CHUNK);
@@ -1507,6 +1552,10 @@ struct hac_index {
     int64_t ntotal = 0;
     // multi-device merge workspace lives on shard 0
     GrowBuf ws_lists, ws_out;
+    // n_dev > 1: per shard, its share of every add() (see remap_positions_kernel)
+    std::vector<std::vector<SpanDesc>> spans;
+    std::vector<GrowBuf> ws_spans;
+    std::vector<char> spans_dirty;
 };
 
 extern "C" {
@@ -1537,6 +1586,9 @@ int hac_index_create(int d, const int *device_ids, int n_dev, hac_index **out) {
         }
         idx->shards.push_back(s);
     }
+    idx->spans.resize(n_dev);
+    idx->ws_spans.resize(n_dev);
+    idx->spans_dirty.assign(n_dev, 1);
     *out = idx;
     return HAC_OK;
 }
@@ -1548,9 +1600,13 @@ void hac_index_destroy(hac_index *idx) {
         idx->ws_lists.release();
         idx->ws_out.release();
     }
-    for (auto *s : idx->shards) {
-        s->destroy();
-        delete s;
+    for (size_t i = 0; i < idx->shards.size(); ++i) {
+        if (i < idx->ws_spans.size()) {
+            DeviceGuard g(idx->shards[i]->device);
+            idx->ws_spans[i].release();
+        }
+        idx->shards[i]->destroy();
+        delete idx->shards[i];
     }
     delete idx;
 }
@@ -1560,11 +1616,20 @@ int hac_index_add(hac_index *idx, const float *x, int64_t n) {
     if (n < 0 || (n > 0 && !x)) return fail(HAC_ERR_INVALID, "add: bad arguments");
     if (n == 0) return HAC_OK;
     const int S = (int)idx->shards.size();
-    // faiss IndexShards(successive_ids): rows of one add() are split contiguously across devices
+    if ((uint64_t)idx->ntotal + (uint64_t)n > 0xFFFFFFFFull) return fail(HAC_ERR_UNSUPPORTED, "row positions exceed 32 bits");
+    // faiss index_cpu_to_gpu_multiple(shard=True): the rows of one add() are split contiguously across the devices;
+    // rows stay numbered by insertion order over the whole index (the per-shard spans translate back)
     int64_t off = 0;
     for (int s = 0; s < S; ++s) {
         const int64_t m = n / S + (s < n % S ? 1 : 0);
-        if (m) HAC_TRY(idx->shards[s]->add_host_rows(x + (size_t)off * idx->d, m));
+        if (m) {
+            const int64_t local0 = idx->shards[s]->ntotal;
+            HAC_TRY(idx->shards[s]->add_host_rows(x + (size_t)off * idx->d, m));
+            if (S > 1) {
+                idx->spans[s].push_back(SpanDesc{(u32)local0, (u32)m, (u32)(idx->ntotal + off), 0u});
+                idx->spans_dirty[s] = 1;
+            }
+        }
         off += m;
     }
     idx->ntotal += n;
@@ -1586,6 +1651,10 @@ int hac_index_add_device(hac_index *idx, const float *x_dev, int64_t n, void *hi
 int hac_index_reset(hac_index *idx) {
     if (!idx) return fail(HAC_ERR_INVALID, "null index");
     for (auto *s : idx->shards) HAC_TRY(s->reset());
+    for (size_t i = 0; i < idx->spans.size(); ++i) {
+        idx->spans[i].clear();
+        idx->spans_dirty[i] = 1;
+    }
     idx->ntotal = 0;
     return HAC_OK;
 }
@@ -1664,18 +1733,54 @@ int hac_index_search(hac_index *idx, const float *q, int64_t nq, int k, float *D
         HAC_TRY(idx->ws_lists.reserve((size_t)S * nq * k * 8));
         HAC_TRY(idx->ws_out.reserve((size_t)nq * k * 8));
     }
-    int64_t base = 0;
-    for (int si = 0; si < S; ++si) {
+    // Every shard searches its own rows on its own stream.  With several devices one host thread per shard drives
+    // its device (the prefilter path reads a status word back per search: in sequence the devices would take turns);
+    // a thread's failure message is carried back to the caller's error slot.
+    auto search_shard = [&](int si) -> int {
         DeviceIndex *s = idx->shards[si];
         DeviceGuard g(s->device);
+        if (!g.ok) return fail(HAC_ERR_HIP, "cannot select HIP device %d", s->device);
         HAC_TRY(s->ws_q.reserve(qbytes));
         HAC_TRY(s->ws_keys.reserve((size_t)nq * k * 8));
         HAC_TRY(s->pin_reserve(std::max(qbytes, (size_t)nq * k * 12)));
         HAC_HIP(hipStreamSynchronize(s->stream));
         std::memcpy(s->h_pin, q, qbytes);
         HAC_HIP(hipMemcpyAsync(s->ws_q.p, s->h_pin, qbytes, hipMemcpyHostToDevice, s->stream));
-        HAC_TRY(s->search_keys((const float *)s->ws_q.p, nq, k, (u64 *)s->ws_keys.p, (u32)base, s->stream));
-        base += s->ntotal;
+        HAC_TRY(s->search_keys((const float *)s->ws_q.p, nq, k, (u64 *)s->ws_keys.p, 0u, s->stream));
+        if (S > 1) {   // shard-local rows -> insertion-order positions of the whole index
+            const std::vector<SpanDesc> &sp = idx->spans[si];
+            if (!sp.empty()) {
+                if (idx->spans_dirty[si]) {
+                    HAC_TRY(idx->ws_spans[si].reserve(sp.size() * sizeof(SpanDesc)));
+                    HAC_HIP(hipStreamSynchronize(s->stream));
+                    HAC_HIP(hipMemcpy(idx->ws_spans[si].p, sp.data(), sp.size() * sizeof(SpanDesc), hipMemcpyHostToDevice));
+                    idx->spans_dirty[si] = 0;
+                }
+                const long nk = (long)nq * k;
+                remap_positions_kernel<<<dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, s->stream>>>(
+                    (u64 *)s->ws_keys.p, nk, (const SpanDesc *)idx->ws_spans[si].p, (int)sp.size());
+                HAC_HIP(hipGetLastError());
+            }
+            HAC_HIP(hipStreamSynchronize(s->stream));
+        }
+        return HAC_OK;
+    };
+    if (S == 1) {
+        HAC_TRY(search_shard(0));
+    } else {
+        std::vector<int> rcs(S, HAC_OK);
+        std::vector<std::string> msgs(S);
+        std::vector<std::thread> pool;
+        for (int si = 1; si < S; ++si)
+            pool.emplace_back([&, si] {
+                rcs[si] = search_shard(si);
+                if (rcs[si] != HAC_OK) msgs[si] = last_error_slot();
+            });
+        rcs[0] = search_shard(0);
+        if (rcs[0] != HAC_OK) msgs[0] = last_error_slot();
+        for (auto &t : pool) t.join();
+        for (int si = 0; si < S; ++si)
+            if (rcs[si] != HAC_OK) return fail(rcs[si], "shard %d (device %d): %s", si, idx->shards[si]->device, msgs[si].c_str());
     }
     DeviceGuard g0(s0->device);
     const uint64_t *final_keys = (const uint64_t *)s0->ws_keys.p;
@@ -1684,7 +1789,6 @@ int hac_index_search(hac_index *idx, const float *q, int64_t nq, int k, float *D
         // streams are non-blocking, a legacy-stream D2D copy would not be ordered with them)
         for (int si = 0; si < S; ++si) {
             DeviceIndex *s = idx->shards[si];
-            if (si) HAC_HIP(hipStreamSynchronize(s->stream));
             HAC_HIP(hipMemcpyAsync((char *)idx->ws_lists.p + (size_t)si * nq * k * 8, s->ws_keys.p, (size_t)nq * k * 8,
                                    hipMemcpyDeviceToDevice, s0->stream));
         }
@@ -1700,6 +1804,12 @@ int hac_index_search(hac_index *idx, const float *q, int64_t nq, int k, float *D
     HAC_HIP(hipStreamSynchronize(s0->stream));
     std::memcpy(I, hp, (size_t)nq * k * 8);
     std::memcpy(D, hp + (size_t)nq * k * 8, (size_t)nq * k * 4);
+    return HAC_OK;
+}
+
+int hac_index_set_option(hac_index *idx, const char *name, const char *value) {
+    if (!idx || !name) return fail(HAC_ERR_INVALID, "set_option: null argument");
+    for (auto *s : idx->shards) HAC_TRY(s->set_option(name, value));
     return HAC_OK;
 }
 

@@ -97,11 +97,27 @@ class ANCEEncoder:
     def to(self, device):
         return self
 
-    def set_profiling(self, on=True):
-        _lib.check(_lib.lib().hac_encoder_set_profiling(self._h, int(bool(on))))
+    KERNEL_CLASSES = ("qkv", "attention", "out_proj", "ffn_up", "ffn_down", "layernorm")   # HAC_ENC_CLASS_* of include/haconvdr.h
+
+    def set_profiling(self, on=True, classes=()):
+        """hipEvent pairs around the layer stack of every forward (``on``) and around every launch of the named
+        kernel classes (``classes``: names from KERNEL_CLASSES, or "all")."""
+        if classes == "all":
+            classes = self.KERNEL_CLASSES
+        mask = int(bool(on))
+        for c in classes:
+            mask |= 2 << self.KERNEL_CLASSES.index(c)
+        _lib.check(_lib.lib().hac_encoder_set_profiling(self._h, mask))
 
     def profile_drain(self, cap=4096):
         buf = (ctypes.c_float * cap)()
         n = ctypes.c_int()
         _lib.check(_lib.lib().hac_encoder_profile_drain(self._h, buf, cap, ctypes.byref(n)))
+        return [float(buf[i]) for i in range(n.value)]
+
+    def profile_drain_class(self, name, cap=16384):
+        """Durations (ms, launch order) of the launches of one kernel class since the last drain."""
+        buf = (ctypes.c_float * cap)()
+        n = ctypes.c_int()
+        _lib.check(_lib.lib().hac_encoder_profile_drain_class(self._h, self.KERNEL_CLASSES.index(name), buf, cap, ctypes.byref(n)))
         return [float(buf[i]) for i in range(n.value)]

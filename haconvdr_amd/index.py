@@ -20,6 +20,17 @@ def _stream_ptr(stream):
     return ctypes.c_void_p(getattr(stream, "cuda_stream", stream))
 
 
+def _keep_alive(t, stream):
+    """The kernels read ``t`` asynchronously on ``stream`` (a torch stream, a raw hipStream_t or None = the
+    current stream): tell the caching allocator, or it may hand the memory out again too early."""
+    import torch
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    elif not hasattr(stream, "cuda_stream"):
+        stream = torch.cuda.ExternalStream(int(stream))
+    t.record_stream(stream)
+
+
 class FlatIPIndex:
     """faiss.IndexFlatIP(d) drop-in: exact fp32 inner product, results ordered by
     (score desc, row asc), padded with -FLT_MAX / -1.
@@ -72,12 +83,13 @@ class FlatIPIndex:
 
     # ---- device-resident variants (torch tensors on the index's GPU) -------
     def add_tensor(self, x, stream=None):
-        """x: torch float32 CUDA tensor [n, d], contiguous."""
+        """x: torch float32 CUDA tensor [n, d], contiguous.  Enqueued on ``stream`` (default: torch's current
+        stream).  The host API (``add`` / ``search``) runs on the index's own stream: synchronize the stream used
+        here before mixing in host-API calls."""
         assert x.is_cuda and x.dtype.is_floating_point and x.dim() == 2 and x.shape[1] == self.d
         x = x.contiguous().float()
         _lib.check(_lib.lib().hac_index_add_device(self._h, ctypes.c_void_p(x.data_ptr()), x.shape[0], _stream_ptr(stream)))
-        # the kernel reads x asynchronously: keep it alive until the stream has passed
-        x.record_stream(__import__("torch").cuda.current_stream()) if stream is None else None
+        _keep_alive(x, stream)
 
     def search_tensor(self, q, k, id_map=None, stream=None):
         """q: torch float32 CUDA [nq, d] -> (D float32 [nq,k], I int64 [nq,k]) CUDA tensors,
@@ -92,6 +104,8 @@ class FlatIPIndex:
         _lib.check(_lib.lib().hac_index_search_device(self._h, ctypes.c_void_p(q.data_ptr()), q.shape[0], int(k),
                                                       ctypes.c_void_p(D.data_ptr()), ctypes.c_void_p(I.data_ptr()), mp,
                                                       _stream_ptr(stream)))
+        for t in (q, D, I):
+            _keep_alive(t, stream)
         return D, I
 
     def search_keys_tensor(self, q, k, pos_base=0, stream=None):
@@ -102,7 +116,14 @@ class FlatIPIndex:
         _lib.check(_lib.lib().hac_index_search_keys_device(self._h, ctypes.c_void_p(q.data_ptr()), q.shape[0], int(k),
                                                            ctypes.c_void_p(keys.data_ptr()), int(pos_base),
                                                            _stream_ptr(stream)))
+        for t in (q, keys):
+            _keep_alive(t, stream)
         return keys
+
+    def set_option(self, name, value):
+        """Tuning / test switch of this handle (include/haconvdr.h: hac_index_set_option), e.g.
+        ``set_option("split", "0")`` = exact fp32 kernels only."""
+        _lib.check(_lib.lib().hac_index_set_option(self._h, str(name).encode(), str(value).encode()))
 
     def set_profiling(self, on=True):
         _lib.check(_lib.lib().hac_index_set_profiling(self._h, int(bool(on))))

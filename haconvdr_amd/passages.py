@@ -177,6 +177,9 @@ def encode_passages(model, passages, out_dir, per_gpu_eval_batch_size=250, n_gpu
             mask_t = (torch.arange(ids.shape[1], device=dev)[None, :] < torch.from_numpy(lens).to(dev)[:, None]).to(torch.int32)
             outs.append(model(ids_t, mask_t))                          # :106-110, stays on the GPU
         emb = torch.cat(outs).cpu().numpy()                            # one D2H per block (the reference syncs per batch, :112)
+        bad = np.flatnonzero(np.isnan(emb).any(axis=1))
+        if bad.size:   # the device path flags a sequence it cannot encode with a NaN row (include/haconvdr.h)
+            raise ValueError(f"passage {lo + int(bad[0])}: empty record or token id outside the vocabulary ({bad.size} bad in block {b})")
         write_embedding_block(out_dir, b, emb, np.arange(lo, hi, dtype=np.int64))   # ids = enumerate index (utils.py:140-143)
         written += hi - lo
         if log_every:

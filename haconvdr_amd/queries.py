@@ -42,7 +42,12 @@ def get_test_query_embedding(model, test_loader, test_type="convqa", device=0, m
             ids[r:r + a.shape[0], :a.shape[1]] = a
             mask[r:r + a.shape[0], :a.shape[1]] = m
             r += a.shape[0]
-        embeddings.append(model(ids.to(dev), mask.to(dev)).cpu().numpy())
+        out = model(ids.to(dev), mask.to(dev)).cpu().numpy()
+        bad = np.flatnonzero(np.isnan(out).any(axis=1))
+        if bad.size:   # the device path flags a sequence it cannot encode with a NaN row (include/haconvdr.h)
+            raise ValueError(f"query {sum(len(e) for e in embeddings) + int(bad[0])}: attention mask is not a non-empty prefix mask "
+                             "or a token id lies outside the vocabulary")
+        embeddings.append(out)
         pend_ids, pend_mask, pend_n = [], [], 0
 
     for batch in test_loader:

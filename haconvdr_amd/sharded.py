@@ -42,9 +42,9 @@ class ShardedSearcher:
 
     def search_keys(self, q, k):
         keys = self._local_keys(q, k, self.shard_base)
-        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
-        if world == 1:
-            return keys
+        if not dist.is_initialized():
+            return keys                                   # a single process holding the whole corpus
+        world = dist.get_world_size(self.group)
         nq, k = keys.shape
         gathered = torch.empty((world * nq, k), dtype=keys.dtype, device=keys.device)   # rank-major slabs
         dist.all_gather_into_tensor(gathered, keys.contiguous(), group=self.group)

@@ -76,7 +76,8 @@ int hac_index_add_device(hac_index *idx, const float *x_dev, int64_t n, void *hi
 
 /* D, I = index.search(query_embeddings, topN) — src/test_HAConvDR_topiocqa.py:102.
  * q: host float32 [nq, d]; D: host float32 [nq, k]; I: host int64 [nq, k]
- * (rows numbered by insertion order since the last reset).  Synchronous.
+ * (rows numbered by insertion order since the last reset, whatever the number of devices).
+ * Synchronous.
  *
  * Result contract of every search entry point: score = k-ordered fp32 fma chain, order =
  * (score desc, row asc), NaN scores never returned, short lists padded -FLT_MAX / -1.
@@ -84,9 +85,10 @@ int hac_index_add_device(hac_index *idx, const float *x_dev, int64_t n, void *hi
  * rows are first screened on the fp16 matrix pipe under a proven error bound, the few
  * candidates are rescored exactly and each query's list is certified complete; queries
  * that cannot be certified are searched again by the exact fp32 kernels.
- * The results are the same bits either way.  Environment: HAC_SPLIT=0 disables the
- * screen, HAC_SPLIT=1 applies it whenever the shape allows (tests).  That path reads a
- * small status word back, so the *_device variants synchronize the stream they are given. */
+ * The results are the same bits either way.  hac_index_set_option(idx, "split", "0") disables
+ * the screen, "1" applies it whenever the shape allows (tests), "auto" decides by size.  That
+ * path reads a small status word back, so the *_device variants synchronize the stream they
+ * are given. */
 int hac_index_search(hac_index *idx, const float *q, int64_t nq, int k, float *D, int64_t *I);
 /* Device/stream variant (single-device index).  id_map_dev (optional, int64
  * [ntotal]) maps row -> external id, fusing `passage_embedding2id[I]` (:110). */
@@ -102,6 +104,11 @@ int hac_index_search_keys_device(hac_index *idx, const float *q_dev, int64_t nq,
 int hac_index_reset(hac_index *idx);
 /* index.ntotal */
 int64_t hac_index_ntotal(const hac_index *idx);
+
+/* Tuning and test switches of a live handle: "split" = "0" | "1" | "auto", "split_terms" = "1" | "3",
+ * "force_scan16" = "0" | "1", "scanq_nt" = "0".."4", "scanq_waves" = "4" | "8", "scan_no_p8" = "0" | "1".
+ * The HAC_<NAME> environment variables give the defaults and are read once, in hac_index_create. */
+int hac_index_set_option(hac_index *idx, const char *name, const char *value);
 
 /* Profiling aid for bench.py: when enabled, the main scan kernel of every search is
  * bracketed by a hipEvent pair recorded on the launch stream (no host sync).
@@ -152,16 +159,34 @@ int hac_encoder_set_weight(hac_encoder *enc, const char *name, const float *data
 /* Checks that every tensor is present and packs the GEMM weights to bf16. */
 int hac_encoder_finalize(hac_encoder *enc);
 /* ids, mask: host int32 [B, L]; mask must be a prefix mask (first len >= 1 ones) as both
- * reference pipelines produce (gen_doc_embeddings.py:38-40, src/data.py:8-23); out: host float32
- * [B, 768].  Synchronous. */
+ * reference pipelines produce (gen_doc_embeddings.py:38-40, src/data.py:8-23), attended ids in
+ * [0, vocab); out: host float32 [B, 768].  Synchronous.  HAC_ERR_INVALID names the first bad sequence. */
 int hac_encoder_forward(hac_encoder *enc, const int32_t *ids, const int32_t *mask, int B, int L, float *out);
 /* Device/stream variant: ids/mask device pointers of elem_bytes 4 (int32) or 8 (int64, what the
- * reference passes); out_dev float32 [B,768].  A non-prefix mask yields NaN rows. */
+ * reference passes); out_dev float32 [B,768].  Work is enqueued on hip_stream.  A batch of more than
+ * 262144 padded rows (B * roundup(L,32)) runs as several sub-batches sized by the real lengths: that
+ * costs ONE read-back of B ints, i.e. the call synchronizes hip_stream once (not capturable); smaller
+ * batches never synchronize.  Errors the device finds are reported per sequence: a mask that is not
+ * a non-empty prefix mask, or an attended token id outside [0, vocab) (nn.Embedding would raise),
+ * yields a NaN row for THAT sequence only; the host variant turns such a row into HAC_ERR_INVALID. */
 int hac_encoder_forward_device(hac_encoder *enc, const void *ids_dev, const void *mask_dev, int elem_bytes,
                                int B, int L, float *out_dev, void *hip_stream);
-/* hipEvent pairs around the 12-layer stack of each forward (bench.py). */
-int hac_encoder_set_profiling(hac_encoder *enc, int enable);
+/* Profiling aid for bench.py: hipEvent pairs recorded on the launch stream (no host sync).  mask bit 0:
+ * around the layer stack of each forward (sub-batch); bit 1+c: around every launch of kernel class c.
+ * hac_encoder_profile_drain / _drain_class wait for the recorded pairs, write up to cap durations (ms, in
+ * launch order) and clear the record. */
+enum {
+    HAC_ENC_CLASS_QKV = 0,       /* gemm_bf16_nt_kernel<EPI_QKV>:   [T,768] x [2304,768]^T + bias, Q scale, V regrouping */
+    HAC_ENC_CLASS_ATTN = 1,      /* attention_kernel<4|8> (both launches of a layer) */
+    HAC_ENC_CLASS_OUTPROJ = 2,   /* gemm_bf16_nt_kernel<EPI_RESID>: [T,768] x [768,768]^T + bias + residual (+ LayerNorm statistics) */
+    HAC_ENC_CLASS_FFN_UP = 3,    /* gemm_bf16_nt_kernel<EPI_GELU>:  [T,768] x [3072,768]^T + bias + erf GELU */
+    HAC_ENC_CLASS_FFN_DOWN = 4,  /* gemm_bf16_nt_kernel<EPI_RESID>: [T,3072] x [768,3072]^T + bias + residual (+ LayerNorm statistics) */
+    HAC_ENC_CLASS_LN = 5,        /* LayerNorm passes that are their own kernel */
+    HAC_ENC_NCLASS = 6
+};
+int hac_encoder_set_profiling(hac_encoder *enc, int mask);
 int hac_encoder_profile_drain(hac_encoder *enc, float *ms_out, int cap, int *n_out);
+int hac_encoder_profile_drain_class(hac_encoder *enc, int cls, float *ms_out, int cap, int *n_out);
 
 #ifdef __cplusplus
 }

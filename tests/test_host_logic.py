@@ -141,3 +141,16 @@ def test_trec_metrics_hand_worked(tmp_path):
     res2 = print_trec_res(str(run), str(qrel), rel_threshold=2)
     assert res2["MRR"] == round((1 / 2 + 0.0) / 2 * 100, 5)
     assert res2["Recall@10"] == round((1.0 + 0.0) / 2 * 100, 5)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` with no launcher: the parent starts N ranks (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set, loopback rendezvous), waits for all of them, and fails when a rank fails."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--spawn-selftest"]
+    ok = subprocess.run(cmd + ["0"], capture_output=True, text=True, timeout=120)
+    assert ok.returncode == 0, ok.stderr
+    lines = sorted(l for l in ok.stdout.splitlines() if l.startswith("selftest"))
+    assert [l.split()[2] for l in lines] == ["0", "1", "2"] and all(" of 3 " in l for l in lines)
+    assert len({l.split()[-1] for l in lines}) == 1           # one rendezvous port for all ranks
+    bad = subprocess.run(cmd + ["7"], capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 7

@@ -192,27 +192,48 @@ def test_errors_are_loud(index):
 
 
 def test_in_process_shards_same_device(oracle):
-    """faiss shard=True semantics (:55-66) with two shards on the one GPU of the test box:
-    rows of every add() are split contiguously, per-shard top-k merged on device."""
+    """faiss shard=True semantics (:55-66) with three shards on the one GPU of the test box: the rows of every
+    add() are split contiguously across the shards, per-shard top-k merged on device, and rows stay numbered
+    by insertion order over the whole index (the duplicated rows of the "dup" case tie across shards: the
+    earlier row must win)."""
     from haconvdr_amd.index import FlatIPIndex
     x, q, _ = cases.search_case_inputs("dup", 31337, 3000, 6)
     idx = FlatIPIndex(768, devices=(0, 0, 0))
     idx.add(x[:1000])
-    idx.add(x[1000:])
+    idx.add(x[1000:1001])          # a one-row add: two shards get nothing from it
+    idx.add(x[1001:])
     assert idx.ntotal == 3000
-    D, I = idx.search(q, 100)
-    # global row numbering of the sharded index: shard s holds [its part of add 1, its part of add 2]
-    parts = [[], [], []]
-    for lo, hi in ((0, 1000), (1000, 3000)):
-        n = hi - lo
-        off = lo
-        for s in range(3):
-            m = n // 3 + (1 if s < n % 3 else 0)
-            parts[s].append(np.arange(off, off + m))
-            off += m
-    order = np.concatenate([np.concatenate(p) for p in parts])
-    oD, oI = oracle.flat_ip_search(x[order], q, 100)
-    assert_same(D, I, oD, oI)
+    assert_same(*idx.search(q, 100), *oracle.flat_ip_search(x, q, 100))
+    q2 = cases.search_case_inputs("gauss", 5, 1, 96)[1]                 # the prefilter path per shard
+    idx.set_option("split", "1")
+    assert_same(*idx.search(q2, 100), *oracle.flat_ip_search(x, q2, 100))
+    idx.reset()
+    idx.add(x[:70])
+    assert_same(*idx.search(q, 100), *oracle.flat_ip_search(x[:70], q, 100))   # fewer rows than k, spans rebuilt after reset
+
+
+@pytest.mark.parametrize("devices", [(0, 0), (0, 1)])
+def test_search_one_by_one_on_a_multi_device_index(devices, oracle, tmp_path):
+    """build_index(args) with n_gpu > 1 through the reference's block loop: >= 2 resident blocks with distinct
+    passage ids on a two-shard index == the reference's merge (ids, float64 scores, earlier block wins ties)."""
+    import torch
+    from types import SimpleNamespace
+    from haconvdr_amd import passages
+    from haconvdr_amd.index import FlatIPIndex
+    from haconvdr_amd.search import search_one_by_one
+    if max(devices) >= torch.cuda.device_count():
+        pytest.skip("needs %d GPUs" % (max(devices) + 1))
+    x, q, ids = cases.search_case_inputs("dup", 4711, 2500, 9)
+    bounds = [0, 700, 1500, 2500]
+    blocks = [(x[a:b], ids[a:b]) for a, b in zip(bounds[:-1], bounds[1:])]
+    for b, (emb, bid) in enumerate(blocks):
+        passages.write_embedding_block(str(tmp_path), b, emb, bid)
+    idx = FlatIPIndex(768, devices=devices)
+    args = SimpleNamespace(passage_block_num=len(blocks))
+    D, I = search_one_by_one(args, str(tmp_path), idx, q, 100)
+    mD, mI = oracle.search_one_by_one(blocks, q, 100)
+    np.testing.assert_array_equal(I, mI[:, :100])
+    np.testing.assert_array_equal(D, mD[:, :100])
 
 
 def test_merge_keys_matches_reference_merge(oracle):
@@ -322,10 +343,10 @@ def test_scan16_and_scanq_agree(oracle, monkeypatch):
     idx = FlatIPIndex(768)
     idx.add(x)
     D1, I1 = idx.search(q, 100)
-    monkeypatch.setenv("HAC_FORCE_SCAN16", "1")
+    idx.set_option("force_scan16", "1")
     D2, I2 = idx.search(q, 100)
-    monkeypatch.delenv("HAC_FORCE_SCAN16")
-    monkeypatch.setenv("HAC_SCANQ_WAVES", "4")
+    idx.set_option("force_scan16", "0")
+    idx.set_option("scanq_waves", "4")
     D3, I3 = idx.search(q, 100)
     oD, oI = oracle.flat_ip_search(x, q, 100)
     for D, I in ((D1, I1), (D2, I2), (D3, I3)):
@@ -369,6 +390,92 @@ def test_cfg3_block_size_properties(oracle):
         np.testing.assert_array_equal(D[s].cpu().numpy(), oD[:len(s)])
 
 
+def _std_rows(gen, n):
+    import torch
+    x = torch.randn((n, 768), generator=gen, device="cuda")
+    return (x - x.mean(1, keepdim=True)) / x.std(1, unbiased=False, keepdim=True)
+
+
+def test_cfg3_full_residency_25m_rows(oracle):
+    """BASELINE.json configs[2] at full size: 25M x 768 in 8 resident passage blocks of 3.125M rows (76.8 GB of
+    HBM), 1000 queries, top-100.  Oracle on four queries, computed block by block and merged with the reference's
+    own merge step (oracle_merge_step = src/test_HAConvDR_qrecc.py:131-149); size-independent properties on all."""
+    import torch
+    from haconvdr_amd.index import FlatIPIndex
+    N, NB, K, NQ = 25_000_000, 8, 100, 1000
+    gen = torch.Generator(device="cuda").manual_seed(0xC0FFEE + 25)
+    q = _std_rows(gen, NQ)
+    sel = [0, 1, 500, 999]
+    qs = q[sel].cpu().numpy()
+    idx = FlatIPIndex(768)
+
+    def blocks():          # one block on the host at a time (9.6 GB); the index keeps all eight
+        for b in range(NB):
+            xb = _std_rows(gen, N // NB)
+            idx.add_tensor(xb)
+            torch.cuda.synchronize()
+            yield xb.cpu().numpy(), np.arange(b * (N // NB), (b + 1) * (N // NB), dtype=np.int64)
+            del xb
+
+    mD, mI = oracle.search_one_by_one(blocks(), qs, K)
+    assert idx.ntotal == N
+    D, I = idx.search_tensor(q, K)
+    torch.cuda.synchronize()
+    assert idx.last_plan().startswith("split:")
+    assert bool((D[:, :-1] >= D[:, 1:]).all()) and int(I.min()) >= 0 and int(I.max()) < N
+    assert all(len(set(r)) == K for r in I[::97].cpu().tolist())
+    np.testing.assert_array_equal(I[sel].cpu().numpy(), mI)
+    np.testing.assert_array_equal(D[sel].cpu().numpy().astype(np.float64), mD)
+    # the HBM-bound regime (16 queries per corpus pass, scan16_kernel) and the exact many-query kernels give the same bits
+    D16, I16 = idx.search_tensor(q[:16], K)
+    assert idx.last_plan().startswith("scan16")
+    assert torch.equal(I16, I[:16]) and torch.equal(D16, D[:16])
+    idx.set_option("split", "0")
+    D64, I64 = idx.search_tensor(q[:64], K)
+    assert idx.last_plan().startswith("scanq")
+    assert torch.equal(I64, I[:64]) and torch.equal(D64, D[:64])
+
+
+def test_cfg4_shard_under_an_nccl_group(oracle):
+    """BASELINE.json configs[3]: one 6.75M-row shard of the 54M-row corpus (rank 3 of 8: global rows 20.25M ...),
+    searched through ShardedSearcher with its HIP defaults inside a (one-rank) RCCL process group: local top-k keys
+    with global positions -> all_gather_into_tensor -> hac_merge_keys_device -> results.  Oracle on four queries."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from haconvdr_amd.index import FlatIPIndex
+    from haconvdr_amd.sharded import ShardedSearcher, shard_range
+    lo, hi = shard_range(54_000_000, 3, 8)
+    assert hi - lo == 6_750_000
+    gen = torch.Generator(device="cuda").manual_seed(0xC0FFEE + 54)
+    idx = FlatIPIndex(768)
+    host = []
+    for _ in range(6):
+        xb = _std_rows(gen, (hi - lo) // 6)
+        idx.add_tensor(xb)
+        host.append(xb.cpu().numpy())
+        del xb
+    q = _std_rows(gen, 1000)
+    sel = [0, 7, 512, 999]
+    oD, oI = oracle.flat_ip_search(np.concatenate(host), q[sel].cpu().numpy(), 100)
+    del host
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        D, I = ShardedSearcher(idx, shard_base=lo).search(q, 100)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    assert idx.last_plan().startswith("split:")
+    assert int(I.min()) >= lo and int(I.max()) < hi and bool((D[:, :-1] >= D[:, 1:]).all())
+    np.testing.assert_array_equal(I[sel].cpu().numpy(), oI + lo)
+    np.testing.assert_array_equal(D[sel].cpu().numpy(), oD)
+    D1, I1 = ShardedSearcher(idx, shard_base=lo).search(q, 100)      # no process group: same answer
+    assert torch.equal(I1, I) and torch.equal(D1, D)
+
+
 def test_resident_corpus_many_searches(tmp_path, oracle):
     """Blocks loaded once (zero-copy mmap of the pickled payload), searched repeatedly."""
     from haconvdr_amd.passages import write_embedding_block
@@ -403,17 +510,17 @@ def test_split_prefilter_equals_exact_and_oracle(n, nq, k, terms, oracle, monkey
     """Forced through the prefilter (HAC_SPLIT=1; one fp16 product per score, or three) vs forced off
     (HAC_SPLIT=0): identical ids and scores; on random data the certificate holds for (nearly) every
     query and the measured |approx - canonical| stays far inside the proven bound."""
-    monkeypatch.setenv("HAC_SPLIT_TERMS", terms)
     from haconvdr_amd.index import FlatIPIndex
     x, q, _ = cases.search_case_inputs("gauss", 7000 + n, n, nq)
     idx = FlatIPIndex(768)
+    idx.set_option("split_terms", terms)
     idx.add(x[: n // 3])           # three segments, the last group partial
     idx.add(x[n // 3: n // 2])
     idx.add(x[n // 2:])
-    monkeypatch.setenv("HAC_SPLIT", "0")
+    idx.set_option("split", "0")
     D0, I0 = idx.search(q, k)
     assert not idx.last_plan().startswith("split:")
-    monkeypatch.setenv("HAC_SPLIT", "1")
+    idx.set_option("split", "1")
     D1, I1 = idx.search(q, k)
     nfail, nq_, ratio = _plan_fields(idx)
     assert nq_ == nq and nfail <= nq // 20, idx.last_plan()
@@ -429,7 +536,7 @@ def test_split_prefilter_unsupported_shapes_take_the_exact_kernels(monkeypatch):
     x, q, _ = cases.search_case_inputs("gauss", 91, 3000, 64)
     idx = FlatIPIndex(768)
     idx.add(x)
-    monkeypatch.setenv("HAC_SPLIT", "1")
+    idx.set_option("split", "1")
     idx.search(q, 193)                       # k beyond the candidate lists' margin
     assert not idx.last_plan().startswith("split:")
     idx.reset()
@@ -442,11 +549,11 @@ def test_split_prefilter_ties_and_degenerate_data_fall_back(oracle, monkeypatch)
     """Data the certificate cannot vouch for: exact duplicates around the k-th score, all-equal scores,
     NaN / Inf rows, a zero query.  Those queries are re-run by the exact kernels; the answer is the oracle's."""
     from haconvdr_amd.index import FlatIPIndex
-    monkeypatch.setenv("HAC_SPLIT", "1")
     x, q, _ = cases.search_case_inputs("gauss", 4242, 6000, 80)
     # (a) every row duplicated 600 times: ties far wider than the candidate lists
     xd = np.tile(x[:10], (600, 1))
     idx = FlatIPIndex(768)
+    idx.set_option("split", "1")
     idx.add(xd)
     D, I = idx.search(q, 100)
     nfail, _, _ = _plan_fields(idx)
@@ -477,9 +584,10 @@ def test_split_prefilter_keys_with_pos_base_and_shards(oracle, monkeypatch):
     """search_keys (the sharded / multi-block entry) through the prefilter: global positions, merge."""
     import torch
     from haconvdr_amd.index import FlatIPIndex, merge_keys, keys_to_results
-    monkeypatch.setenv("HAC_SPLIT", "1")
     x, q, _ = cases.search_case_inputs("gauss", 31337, 30000, 96)
     h1, h2 = FlatIPIndex(768), FlatIPIndex(768)
+    h1.set_option("split", "1")
+    h2.set_option("split", "1")
     h1.add(x[:13000])
     h2.add(x[13000:])
     qt = torch.from_numpy(q).cuda()
@@ -495,13 +603,13 @@ def test_split_prefilter_cascade_escalates_to_three_products(oracle, monkeypatch
     noise): the first level cannot certify them, the three-product level (or, past it, the exact kernels)
     decides -- same answer as the oracle."""
     from haconvdr_amd.index import FlatIPIndex
-    monkeypatch.setenv("HAC_SPLIT", "1")
     rng = np.random.default_rng(99)
     base = cases.search_case_inputs("gauss", 5, 1, 1)[0][0]
     x = (base[None, :] + 0.03 * rng.standard_normal((8000, 768))).astype(np.float32)
     q = cases.search_case_inputs("gauss", 6, 1, 96)[1]
     q = (q + 0.5 * base[None, :]).astype(np.float32)
     idx = FlatIPIndex(768)
+    idx.set_option("split", "1")
     idx.add(x)
     D, I = idx.search(q, 100)
     plan = idx.last_plan()
@@ -521,9 +629,9 @@ def test_split_prefilter_other_dimensions(d, oracle, monkeypatch):
     q = rng.standard_normal((150, d)).astype(np.float32)
     idx = FlatIPIndex(d)
     idx.add(x)
-    monkeypatch.setenv("HAC_SPLIT", "0")
+    idx.set_option("split", "0")
     D0, I0 = idx.search(q, 50)
-    monkeypatch.setenv("HAC_SPLIT", "1")
+    idx.set_option("split", "1")
     D1, I1 = idx.search(q, 50)
     if d >= 128:
         assert idx.last_plan().startswith("split:"), idx.last_plan()
@@ -542,7 +650,7 @@ def test_large_query_sets_are_chunked(oracle, monkeypatch):
     idx = FlatIPIndex(768)
     idx.add(x)
     D1, I1 = idx.search(q, 20)                # default policy: prefilter per chunk (40k x 1024 pairs < 1e8 -> exact kernels)
-    monkeypatch.setenv("HAC_SPLIT", "1")
+    idx.set_option("split", "1")
     D2, I2 = idx.search(q, 20)
     assert idx.last_plan().startswith("split:")
     assert_same(D2, I2, D1, I1)
@@ -576,9 +684,9 @@ def test_split_prefilter_value_ranges(kind, oracle, monkeypatch):
         q += np.float32(1.0)
     idx = FlatIPIndex(d)
     idx.add(x)
-    monkeypatch.setenv("HAC_SPLIT", "0")
+    idx.set_option("split", "0")
     D0, I0 = idx.search(q, k)
-    monkeypatch.setenv("HAC_SPLIT", "1")
+    idx.set_option("split", "1")
     D1, I1 = idx.search(q, k)
     assert idx.last_plan().startswith("split:"), idx.last_plan()
     _, _, ratio = _plan_fields(idx)
@@ -627,10 +735,10 @@ def test_split_prefilter_randomized_differential(monkeypatch):
         cuts = sorted(set([0, n] + [int(v) for v in rng.integers(1, n, int(rng.integers(0, 3)))]))
         for a, b in zip(cuts[:-1], cuts[1:]):
             idx.add(x[a:b])
-        monkeypatch.setenv("HAC_SPLIT", "0")
+        idx.set_option("split", "0")
         D0, I0 = idx.search(q, k)
-        monkeypatch.setenv("HAC_SPLIT", "1")
-        monkeypatch.setenv("HAC_SPLIT_TERMS", str(rng.choice(["1", "3"])))
+        idx.set_option("split", "1")
+        idx.set_option("split_terms", str(rng.choice(["1", "3"])))
         D1, I1 = idx.search(q, k)
         plan = idx.last_plan()
         assert plan.startswith("split:"), (case, plan)
