@@ -393,6 +393,7 @@ def cpu_baseline(np, torch, synth, enc, D, I, q_pre, kept, rows, nq, k, Lq, tok)
     os.environ["OMP_NUM_THREADS"] = str(cores)
     xh = np.concatenate(kept)[:1_000_000]
     n_slice = xh.shape[0]
+    omp_threads = oracle.num_threads()
     try:
         import faiss  # noqa: F401
         faiss_note = "importable: version " + getattr(faiss, "__version__", "?")
@@ -409,7 +410,7 @@ def cpu_baseline(np, torch, synth, enc, D, I, q_pre, kept, rows, nq, k, Lq, tok)
         ts.append(time.perf_counter() - tp)
     t_search_q = float(np.median(ts)) / nq_s * (rows / n_slice)
     search = {"queries_per_sec_over_slice": round(nq_s / float(np.median(ts)), 2), "slice_rows": n_slice, "queries": nq_s,
-              "runs_s": [round(t, 3) for t in ts], "threads": oracle.num_threads()}
+              "runs_s": [round(t, 3) for t in ts], "threads": omp_threads}
     CPU_RESULT["slice"] = (oD, oI)
     if faiss is not None:
         fi = faiss.IndexFlatIP(D_EMB)
@@ -455,7 +456,7 @@ def cpu_baseline(np, torch, synth, enc, D, I, q_pre, kept, rows, nq, k, Lq, tok)
     res["value"] = round(1.0 / (t_enc_q + t_search_q), 3)
     res["cores"] = cores
     res["sample"] = (f"encode: {n_s} of the {nq} queries (L={Lq}) through oracle/ance_oracle.py (fp32 torch CPU ops, {best[0]} threads); search: "
-                     f"{nq_s} queries over a {n_slice}-row slice through oracle/flat_ip_oracle.c (OpenMP, {oracle.num_threads()} threads), scaled "
+                     f"{nq_s} queries over a {n_slice}-row slice through oracle/flat_ip_oracle.c (OpenMP, {omp_threads} threads), scaled "
                      f"x{rows / n_slice:g} to {rows} rows; each the median of 5 runs after a warm-up; value = 1 / (encode s/query + search s/query)")
     return res
 
