@@ -592,6 +592,8 @@ __global__ __launch_bounds__(TMT * 128, 2) void gemm_bf16_nt_kernel(GemmArgs g) 
     }
 }
 
+#include "gemm8.inc"
+
 // ------------------------------------------------------------------ attention
 struct AttnArgs {
     const bf16 *q, *k;   // q (pre-scaled by log2(e)/8), k: [Mp][768]
@@ -787,7 +789,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void attention_kern
 // Last layer: everything after attention is only needed for the <s> row of each sequence
 // (masked_mean_or_first with use_mean=False, src/models.py:52-56): gather those B rows into compact
 // matrices and run out-proj, LN, FFN, LN on B rows instead of T.
-__global__ __launch_bounds__(256) void gather_cls_kernel(const bf16 *__restrict__ ctx, const float *__restrict__ x, const float2 *__restrict__ xstats,
+__global__ __launch_bounds__(256) void gather_cls_kernel(const bf16 *__restrict__ ctx, const float *__restrict__ x, const bf16 *__restrict__ x16, const float2 *__restrict__ xstats,
                                                          const float *__restrict__ xgamma, const float *__restrict__ xbeta, SeqInfo s, int B,
                                                          bf16 *__restrict__ ctx_c, float *__restrict__ x_c) {
     const int b = blockIdx.x;
@@ -802,7 +804,7 @@ __global__ __launch_bounds__(256) void gather_cls_kernel(const bf16 *__restrict_
         }
         for (int i = tid; i < H; i += 256) {
             ctx_c[(size_t)b * H + i] = ctx[row * H + i];
-            const float v = x[row * H + i];
+            const float v = x16 ? (float)x16[row * H + i] : x[row * H + i];   // the large-batch path keeps the residual stream in bf16
             x_c[(size_t)b * H + i] = xstats ? (v - mean) * rstd * xgamma[i] + xbeta[i] : v;
         }
     } else {  // padding rows of the compact matrices feed the GEMM tiles: keep them finite
@@ -876,6 +878,9 @@ struct LayerW {
     bf16 *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;
     float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
     float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr;
+    // large-batch path (gemm8.inc): the preceding LayerNorm folded into the weights that consume its output
+    bf16 *wqkv8 = nullptr, *w18 = nullptr;      // [2304][768] (q rows also carry log2(e)/8), [3072][768]
+    float *fold = nullptr;                      // wsum_qkv[2304] | cvec_qkv[2304] | wsum_1[3072] | cvec_1[3072]
 };
 
 }  // namespace
@@ -892,6 +897,9 @@ struct hac_encoder {
     bool finalized = false;
     // workspace
     GrowBuf ws_x, ws_xb, ws_q, ws_k, ws_vt, ws_ctx, ws_y, ws_h, ws_seq, ws_ids, ws_mask, ws_out, ws_cls, ws_stats;
+    GrowBuf ws_yb, ws_part, ws_idstats;   // gemm8 path: bf16 copy of the attention-block rows, row-sum partials, (0, 1) statistics
+    size_t idstats_rows = 0;
+    int gemm_mode = -1;                   // -1: by size, 0: classic kernels only, 1: gemm8 whenever the batch has a full tile (tests)
     void *h_pin = nullptr;
     size_t h_pin_bytes = 0;
     int *h_len = nullptr;      // pinned: padded lengths of a forward that runs as several sub-batches
@@ -993,6 +1001,8 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
     HAC_HIP(hipGetLastError());
     // tile choice: 256^2 tiles once they fill the chip, 128^2 tiles for small batches; persistent grids
     const bool big = (Mp / 256) * (H / 256) >= 128;
+    // large batches: the ping-pong GEMM with the LayerNorms folded into the consuming weights (gemm8.inc)
+    const bool g8 = e->gemm_mode == 1 || (e->gemm_mode < 0 && big);
     const int bt = big ? 256 : 128;
     const size_t lds = (size_t)4 * bt * 128 + (size_t)(big ? 8 : 4) * 4096;   // 2 stages + per-wave patches
     const dim3 blk(big ? 512 : 256);
@@ -1004,6 +1014,21 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
         else gemm_bf16_nt_kernel<EPI, 2><<<dim3(n_wg), blk, lds, st>>>(g);             \
         HAC_TRY(prof_end(e, 1 + (CLS), st));                                          \
     } while (0)
+    bf16 *yAb = nullptr;
+    float2 *part = nullptr, *idstats = nullptr;
+    if (g8) {
+        HAC_TRY(e->ws_yb.reserve((size_t)Mp * H * 2));
+        HAC_TRY(e->ws_part.reserve((size_t)Mp * (H / 64) * 8));
+        if (e->idstats_rows < (size_t)Mp) {
+            HAC_TRY(e->ws_idstats.reserve((size_t)Mp * 8));
+            e->idstats_rows = e->ws_idstats.cap / 8;
+            fill_identity_stats_kernel<<<dim3((unsigned)((e->idstats_rows + 255) / 256)), dim3(256), 0, st>>>((float2 *)e->ws_idstats.p, e->idstats_rows);
+            HAC_HIP(hipGetLastError());
+        }
+        yAb = (bf16 *)e->ws_yb.p;
+        part = (float2 *)e->ws_part.p;
+        idstats = (float2 *)e->ws_idstats.p;
+    }
     HAC_TRY(prof_begin(e, 0, st));
     // compact buffers of the CLS-only tail of the last layer
     const long Mc = ((long)B + MT - 1) / MT * MT;
@@ -1019,9 +1044,25 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
         const bool last = (li == c.n_layers - 1);
         GemmArgs g{};
         g.total_rows = total;
+        Gemm8Args g8a{};
+        g8a.total_rows = total;
+        g8a.skew_ticks = 100;   // 1 us between the XCDs' starts (measured: 0 -> 100 ticks: FFN-up -9 %, out-proj -9 %; 200-400 the same, 800 worse)
+        const dim3 grid8((unsigned)e->n_cu), blk8(512);
+        const size_t lds8 = 131072;
         // QKV
-        g.A = xb; g.W = w.wqkv; g.bias = w.bqkv; g.N = 3 * H; g.K = H; g.q = q; g.k = k; g.v16 = vt;
-        HAC_GEMM(EPI_QKV, HAC_ENC_CLASS_QKV);
+        if (g8) {
+            // A = the previous layer's un-normalized output rows (bf16) + their statistics; layer 0: the normalized embedding rows
+            HAC_TRY(prof_begin(e, 1 + HAC_ENC_CLASS_QKV, st));
+            g8a.A = xb; g8a.K = H; g8a.astats = li ? statsF : idstats;
+            g8a.W = w.wqkv8; g8a.N = 2 * H; g8a.wsum = w.fold; g8a.cvec = w.fold + 3 * H; g8a.q = q; g8a.k = k;
+            gemm8_kernel<EPI8_QK><<<grid8, blk8, lds8, st>>>(g8a);
+            g8a.W = w.wqkv8 + (size_t)2 * H * H; g8a.N = H; g8a.wsum = w.fold + 2 * H; g8a.cvec = w.fold + 5 * H; g8a.v16 = vt;
+            gemm8_kernel<EPI8_V><<<grid8, blk8, lds8, st>>>(g8a);
+            HAC_TRY(prof_end(e, 1 + HAC_ENC_CLASS_QKV, st));
+        } else {
+            g.A = xb; g.W = w.wqkv; g.bias = w.bqkv; g.N = 3 * H; g.K = H; g.q = q; g.k = k; g.v16 = vt;
+            HAC_GEMM(EPI_QKV, HAC_ENC_CLASS_QKV);
+        }
         AttnArgs a{q, k, vt, ctx, s, last ? 1 : 0};
         // sequences of <= 256 rows: 4-wave workgroups; longer ones: 8-wave workgroups (each skips the other's)
         HAC_TRY(prof_begin(e, 1 + HAC_ENC_CLASS_ATTN, st));
@@ -1033,7 +1074,31 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
         // attention block.  yF shares x's buffer (x is dead once layer 0's out-projection has read it).
         const bool defer_in = li > 0;
         const float *ln2g_prev = defer_in ? e->layers[li - 1].ln2g : nullptr, *ln2b_prev = defer_in ? e->layers[li - 1].ln2b : nullptr;
-        if (!last) {
+        if (!last && g8) {
+            // attention output projection + residual -> yA (bf16) and row-sum partials of its fp32 values -> (mean, rstd)
+            g8a.A = ctx; g8a.W = w.wo; g8a.N = H; g8a.K = H; g8a.cvec = w.bo; g8a.resid = xb; g8a.yb = yAb; g8a.part = part;
+            g8a.rstats = defer_in ? statsF : nullptr; g8a.rgamma = ln2g_prev; g8a.rbeta = ln2b_prev;
+            HAC_TRY(prof_begin(e, 1 + HAC_ENC_CLASS_OUTPROJ, st));
+            gemm8_kernel<EPI8_RESID><<<grid8, blk8, lds8, st>>>(g8a);
+            HAC_TRY(prof_end(e, 1 + HAC_ENC_CLASS_OUTPROJ, st));
+            HAC_TRY(prof_begin(e, 1 + HAC_ENC_CLASS_LN, st));
+            ln_combine_kernel<<<dim3((unsigned)(Mp / 256)), dim3(256), 0, st>>>(part, H / 64, H, total, c.ln_eps, statsA);
+            HAC_TRY(prof_end(e, 1 + HAC_ENC_CLASS_LN, st));
+            // FFN up: A = bf16(yA), the attention LayerNorm folded into W1
+            g8a.A = yAb; g8a.astats = statsA; g8a.W = w.w18; g8a.N = FF; g8a.K = H; g8a.wsum = w.fold + 6 * H; g8a.cvec = w.fold + 6 * H + FF; g8a.h = h;
+            HAC_TRY(prof_begin(e, 1 + HAC_ENC_CLASS_FFN_UP, st));
+            gemm8_kernel<EPI8_GELU><<<grid8, blk8, lds8, st>>>(g8a);
+            HAC_TRY(prof_end(e, 1 + HAC_ENC_CLASS_FFN_UP, st));
+            // FFN down + residual LN1(yA) -> yF (bf16, in xb's buffer: the next layer's A operand and residual), partials
+            g8a.A = h; g8a.W = w.w2; g8a.N = H; g8a.K = FF; g8a.cvec = w.b2; g8a.resid = yAb; g8a.yb = xb;
+            g8a.rstats = statsA; g8a.rgamma = w.ln1g; g8a.rbeta = w.ln1b;
+            HAC_TRY(prof_begin(e, 1 + HAC_ENC_CLASS_FFN_DOWN, st));
+            gemm8_kernel<EPI8_RESID><<<grid8, blk8, lds8, st>>>(g8a);
+            HAC_TRY(prof_end(e, 1 + HAC_ENC_CLASS_FFN_DOWN, st));
+            HAC_TRY(prof_begin(e, 1 + HAC_ENC_CLASS_LN, st));
+            ln_combine_kernel<<<dim3((unsigned)(Mp / 256)), dim3(256), 0, st>>>(part, H / 64, H, total, c.ln_eps, statsF);
+            HAC_TRY(prof_end(e, 1 + HAC_ENC_CLASS_LN, st));
+        } else if (!last) {
             // attention output projection + residual, LN statistics
             g.A = ctx; g.W = w.wo; g.bias = w.bo; g.N = H; g.K = H; g.resid = x; g.y = y;
             g.rstats = defer_in ? statsF : nullptr; g.rgamma = ln2g_prev; g.rbeta = ln2b_prev;
@@ -1052,7 +1117,7 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
             HAC_TRY(prof_end(e, 1 + HAC_ENC_CLASS_LN, st));
         } else {
             // only the <s> row of every sequence continues (B rows instead of T): same kernels, compact matrices
-            gather_cls_kernel<<<dim3((unsigned)Mc), dim3(256), 0, st>>>(ctx, x, defer_in ? statsF : nullptr, ln2g_prev, ln2b_prev, s, B, ctx_c, x_c);
+            gather_cls_kernel<<<dim3((unsigned)Mc), dim3(256), 0, st>>>(ctx, x, g8 ? xb : nullptr, defer_in ? statsF : nullptr, ln2g_prev, ln2b_prev, s, B, ctx_c, x_c);
             const size_t lds_s = (size_t)4 * 128 * 128 + (size_t)4 * 4096;
             const dim3 grid_s((unsigned)(e->n_cu * 2)), blk_s(256);
             g.total_rows = s.nb;
@@ -1144,6 +1209,11 @@ int hac_encoder_create(const hac_encoder_config *cfg, int device, hac_encoder **
     (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_QKV, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
     (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_RESID, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
     (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_GELU, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    (void)hipFuncSetAttribute((const void *)gemm8_kernel<EPI8_QK>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void *)gemm8_kernel<EPI8_V>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void *)gemm8_kernel<EPI8_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void *)gemm8_kernel<EPI8_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    if (const char *m = getenv("HAC_ENC_GEMM")) e->gemm_mode = m[0] == 'c' ? 0 : (m[0] == '8' ? 1 : -1);   // classic | 8phase | auto
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) e->n_cu = prop.multiProcessorCount;
@@ -1160,9 +1230,13 @@ void hac_encoder_destroy(hac_encoder *e) {
     for (auto &l : e->layers)
         for (bf16 *p : {l.wqkv, l.wo, l.w1, l.w2})
             if (p) (void)hipFree(p);
-    for (auto &l : e->layers)
+    for (auto &l : e->layers) {
         if (l.bqkv) (void)hipFree(l.bqkv);
-    for (GrowBuf *b : {&e->ws_x, &e->ws_xb, &e->ws_q, &e->ws_k, &e->ws_vt, &e->ws_ctx, &e->ws_y, &e->ws_h, &e->ws_seq, &e->ws_ids, &e->ws_mask, &e->ws_out, &e->ws_cls, &e->ws_stats})
+        if (l.wqkv8) (void)hipFree(l.wqkv8);
+        if (l.w18) (void)hipFree(l.w18);
+        if (l.fold) (void)hipFree(l.fold);
+    }
+    for (GrowBuf *b : {&e->ws_x, &e->ws_xb, &e->ws_q, &e->ws_k, &e->ws_vt, &e->ws_ctx, &e->ws_y, &e->ws_h, &e->ws_seq, &e->ws_ids, &e->ws_mask, &e->ws_out, &e->ws_cls, &e->ws_stats, &e->ws_yb, &e->ws_part, &e->ws_idstats})
         b->release();
     if (e->h_pin) (void)hipHostFree(e->h_pin);
     if (e->h_len) (void)hipHostFree(e->h_len);
@@ -1208,9 +1282,10 @@ int hac_encoder_finalize(hac_encoder *e) {
     HAC_TRY(get_raw(e, "norm.weight", H, &e->ng));
     HAC_TRY(get_raw(e, "norm.bias", H, &e->nb));
     for (auto &l : e->layers) {
-        for (bf16 *pp : {l.wqkv, l.wo, l.w1, l.w2})
+        for (bf16 *pp : {l.wqkv, l.wo, l.w1, l.w2, l.wqkv8, l.w18})
             if (pp) (void)hipFree(pp);
         if (l.bqkv) (void)hipFree(l.bqkv);
+        if (l.fold) (void)hipFree(l.fold);
     }
     e->layers.assign(c.n_layers, LayerW());
     for (int i = 0; i < c.n_layers; ++i) {
@@ -1244,6 +1319,20 @@ int hac_encoder_finalize(hac_encoder *e) {
         HAC_TRY(get_raw(e, q + "output.dense.bias", H, &l.b2));
         HAC_TRY(get_raw(e, q + "output.LayerNorm.weight", H, &l.ln2g));
         HAC_TRY(get_raw(e, q + "output.LayerNorm.bias", H, &l.ln2b));
+        // large-batch path: fold the LayerNorm in front of QKV (the previous layer's output LayerNorm; layer 0 reads the
+        // already normalized embedding rows) and the one in front of FFN-up (this layer's attention LayerNorm)
+        HAC_HIP(hipMalloc((void **)&l.wqkv8, (size_t)3 * H * H * sizeof(bf16)));
+        HAC_HIP(hipMalloc((void **)&l.w18, (size_t)FF * H * sizeof(bf16)));
+        HAC_HIP(hipMalloc((void **)&l.fold, (size_t)(2 * 3 * H + 2 * FF) * 4));
+        const float *pg = i ? e->layers[i - 1].ln2g : nullptr, *pb = i ? e->layers[i - 1].ln2b : nullptr;
+        const float qscale = 0.125f * 1.44269504088896341f;   // softmax scale / ln 2: the attention kernel works in base 2
+        for (int j = 0; j < 3; ++j)
+            fold_ln_kernel<<<dim3(H), dim3(256), 0, e->stream>>>(ws[j], bs[j], pg, pb, H, j == 0 ? qscale : 1.0f, l.wqkv8 + (size_t)j * H * H,
+                                                                 l.fold + j * H, l.fold + 3 * H + j * H);
+        float *w1f;
+        HAC_TRY(get_raw(e, q + "intermediate.dense.weight", (size_t)FF * H, &w1f));
+        fold_ln_kernel<<<dim3(FF), dim3(256), 0, e->stream>>>(w1f, l.b1, l.ln1g, l.ln1b, H, 1.0f, l.w18, l.fold + 6 * H, l.fold + 6 * H + FF);
+        HAC_HIP(hipGetLastError());
     }
     HAC_HIP(hipStreamSynchronize(e->stream));
     e->finalized = true;
@@ -1296,6 +1385,15 @@ int hac_encoder_forward(hac_encoder *e, const int32_t *ids, const int32_t *mask,
         if (out[i] != out[i])
             return fail(HAC_ERR_INVALID, "forward: sequence %zu: attention_mask must be a non-empty prefix mask (first len ones) and attended token ids "
                                          "must lie in [0, %d)", i / H, e->cfg.vocab);
+    return HAC_OK;
+}
+
+int hac_encoder_set_option(hac_encoder *e, const char *name, const char *value) {
+    if (!e || !name || !value) return fail(HAC_ERR_INVALID, "set_option: null argument");
+    const std::string n(name), v(value);
+    if (n == "gemm") e->gemm_mode = v == "classic" ? 0 : (v == "8phase" ? 1 : -1);
+    else if (n == "max_tokens") e->max_tokens = std::max<long>(4096, atol(value));
+    else return fail(HAC_ERR_INVALID, "unknown encoder option '%s'", name);
     return HAC_OK;
 }
 

@@ -97,6 +97,10 @@ class ANCEEncoder:
     def to(self, device):
         return self
 
+    def set_option(self, name, value):
+        """Tuning / test switch of this handle (include/haconvdr.h: hac_encoder_set_option), e.g. ("gemm", "classic")."""
+        _lib.check(_lib.lib().hac_encoder_set_option(self._h, str(name).encode(), str(value).encode()))
+
     KERNEL_CLASSES = ("qkv", "attention", "out_proj", "ffn_up", "ffn_down", "layernorm")   # HAC_ENC_CLASS_* of include/haconvdr.h
 
     def set_profiling(self, on=True, classes=()):

@@ -171,6 +171,12 @@ int hac_encoder_forward(hac_encoder *enc, const int32_t *ids, const int32_t *mas
  * yields a NaN row for THAT sequence only; the host variant turns such a row into HAC_ERR_INVALID. */
 int hac_encoder_forward_device(hac_encoder *enc, const void *ids_dev, const void *mask_dev, int elem_bytes,
                                int B, int L, float *out_dev, void *hip_stream);
+/* Tuning and test switches of a live handle: "gemm" = "auto" (by batch size) | "classic" (128^2 / 256^2 two-stage
+ * kernels with separate LayerNorm passes) | "8phase" (the large-batch ping-pong kernel with folded LayerNorms whenever
+ * the batch has a whole 256-row tile); "max_tokens" = packed rows per sub-batch.  HAC_ENC_GEMM gives the default of
+ * "gemm" and is read once, in hac_encoder_create. */
+int hac_encoder_set_option(hac_encoder *enc, const char *name, const char *value);
+
 /* Profiling aid for bench.py: hipEvent pairs recorded on the launch stream (no host sync).  mask bit 0:
  * around the layer stack of each forward (sub-batch); bit 1+c: around every launch of kernel class c.
  * hac_encoder_profile_drain / _drain_class wait for the recorded pairs, write up to cap durations (ms, in

@@ -48,6 +48,46 @@ def test_encoder_vs_reference_golden(path):
     assert np.abs(out - ref).max() < 0.25
 
 
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[8:-4] for p in GOLD])
+def test_encoder_large_batch_kernels_vs_reference_golden(path):
+    """The large-batch path (gemm8.inc: ping-pong GEMM, LayerNorms folded into the consuming weights, no LayerNorm
+    passes) forced onto the golden inputs: same bar as the classic kernels."""
+    g = np.load(path)
+    enc = encoder(int(g["n_layers"]))
+    enc.set_option("gemm", "8phase")
+    try:
+        out = enc(g["ids"].astype(np.int32), g["mask"].astype(np.int32))
+    finally:
+        enc.set_option("gemm", "auto")
+    ref = g["ref_out"]
+    d = one_minus_cos(out, ref)
+    assert np.all(d < COS_TOL), d
+    assert np.all(d < COS_EXPECT), d
+    assert np.abs(out - ref).max() < 0.25
+
+
+def test_large_batch_kernels_agree_with_classic_on_every_row_and_are_deterministic():
+    """262k packed rows through both GEMM families (2 layers, rich LayerNorm affines): every one of the 600 embeddings
+    agrees (a mis-placed tile or a racy LDS hand-over would show as a few wrong rows), and the ping-pong kernel gives the
+    same bits when run again (its DMA / barrier protocol does not depend on timing)."""
+    from haconvdr_amd import synth
+    enc = encoder(2)
+    ids, lens = synth.token_batch(77, 600, 512, min_len=300)
+    mask = (np.arange(512)[None, :] < lens[:, None]).astype(np.int32)
+    enc.set_option("gemm", "classic")
+    ref = enc(ids, mask)
+    enc.set_option("gemm", "8phase")
+    try:
+        outs = [enc(ids, mask) for _ in range(3)]
+    finally:
+        enc.set_option("gemm", "auto")
+    assert np.isfinite(outs[0]).all()
+    d = one_minus_cos(outs[0], ref)
+    assert d.max() < 1e-4, (float(d.max()), int(d.argmax()))
+    np.testing.assert_array_equal(outs[0], outs[1])
+    np.testing.assert_array_equal(outs[0], outs[2])
+
+
 def test_encoder_vs_oracle_one_layer():
     """1-layer model: errors cannot hide behind 12 layers of averaging."""
     from haconvdr_amd import synth
@@ -95,19 +135,26 @@ def test_batch_composition_invariance():
     np.testing.assert_array_equal(enc(ids[3:4, :128], mask[3:4, :128]), full[3:4])   # shorter padded length L
 
 
-def test_large_batch_subbatching():
-    """More rows than one sub-batch holds: same embeddings as the small batches."""
+@pytest.mark.parametrize("gemm", ["classic", "8phase"])
+def test_large_batch_subbatching(gemm):
+    """More rows than one sub-batch holds: same embeddings as the small batches (bit for bit within one GEMM family: a
+    row's arithmetic does not depend on its tile or its sub-batch)."""
     from haconvdr_amd import synth
     enc = encoder(2)
-    ids, lens = synth.token_batch(31, 1500, 384, min_len=8)      # 576k padded rows, ~300k real: two length-sized sub-batches
-    mask = (np.arange(384)[None, :] < lens[:, None]).astype(np.int32)
-    out = enc(ids, mask)
-    assert np.isfinite(out).all()
-    sel = [0, 17, 599, 1100, 1499]
-    np.testing.assert_array_equal(out[sel], enc(ids[sel], mask[sel]))
-    full = np.ones((900, 384), np.int32)                          # every sequence full length: 345k rows, split by count
-    outf = enc(ids[:900], full)
-    np.testing.assert_array_equal(outf[[0, 450, 899]], enc(ids[[0, 450, 899]], full[:3]))
+    enc.set_option("gemm", gemm)
+    try:
+        ids, lens = synth.token_batch(31, 1500, 384, min_len=8)      # 576k padded rows, ~300k real: two length-sized sub-batches
+        mask = (np.arange(384)[None, :] < lens[:, None]).astype(np.int32)
+        out = enc(ids, mask)
+        assert np.isfinite(out).all()
+        sel = [0, 17, 599, 1100, 1499]
+        np.testing.assert_array_equal(out[sel], enc(ids[sel], mask[sel]))
+        full = np.ones((900, 384), np.int32)                          # every sequence full length: 345k rows, split by count
+        outf = enc(ids[:900], full)
+        np.testing.assert_array_equal(outf[[0, 450, 899]], enc(ids[[0, 450, 899]], full[:3]))
+    finally:
+        enc.set_option("gemm", "auto")
+    enc = encoder(2)
     from haconvdr_amd._lib import HacError
     bad = mask.copy()
     bad[1400, 2] = 0                                              # a hole in a sequence of the LAST sub-batch
