@@ -155,6 +155,8 @@ def test_large_batch_subbatching(gemm):
     finally:
         enc.set_option("gemm", "auto")
     enc = encoder(2)
+    ids, lens = synth.token_batch(31, 1500, 384, min_len=8)
+    mask = (np.arange(384)[None, :] < lens[:, None]).astype(np.int32)
     from haconvdr_amd._lib import HacError
     bad = mask.copy()
     bad[1400, 2] = 0                                              # a hole in a sequence of the LAST sub-batch
