@@ -53,7 +53,13 @@ class ANCEEncoder:
 
     @classmethod
     def from_pretrained(cls, path, device=0):
-        """Checkpoint directory as ANCE.from_pretrained reads it (:170): pytorch_model.bin or model.safetensors."""
+        """Checkpoint directory as ``ANCE.from_pretrained(model_path, config=RobertaConfig.from_pretrained(model_path))``
+        reads it (src/models.py:113-122): ``config.json`` + ``pytorch_model.bin`` or ``model.safetensors``.
+
+        config.json supplies what the tensors cannot: ``layer_norm_eps`` and ``pad_token_id`` (position ids), and is
+        checked against them — layer count, hidden / FFN / head geometry, vocabulary, positions, activation.  A
+        checkpoint this encoder was not built for is refused here, not mis-encoded."""
+        import json
         import os
         import torch
         st = os.path.join(path, "model.safetensors")
@@ -62,7 +68,29 @@ class ANCEEncoder:
             sd = load_file(st)
         else:
             sd = torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu")
-        return cls.from_state_dict({k: v.float() for k, v in sd.items()}, device=device)
+        sd = {k: v.float() for k, v in sd.items()}
+        kw = {}
+        cfg_path = os.path.join(path, "config.json")
+        if os.path.exists(cfg_path):
+            with open(cfg_path) as f:
+                cfg = json.load(f)
+            n_layers = 1 + max(int(k.split(".")[3]) for k in sd if k.startswith("roberta.encoder.layer."))
+            vocab, hidden = sd["roberta.embeddings.word_embeddings.weight"].shape
+            found = {"num_hidden_layers": n_layers, "hidden_size": hidden, "vocab_size": vocab,
+                     "max_position_embeddings": sd["roberta.embeddings.position_embeddings.weight"].shape[0],
+                     "type_vocab_size": sd["roberta.embeddings.token_type_embeddings.weight"].shape[0],
+                     "intermediate_size": sd["roberta.encoder.layer.0.intermediate.dense.weight"].shape[0]}
+            for key, have in found.items():
+                if key in cfg and int(cfg[key]) != int(have):
+                    raise ValueError(f"{cfg_path}: {key} = {cfg[key]} but the checkpoint's tensors say {have}")
+            if int(cfg.get("num_attention_heads", 12)) != 12 or int(cfg.get("hidden_size", 768)) != 768 or int(cfg.get("intermediate_size", 3072)) != 3072:
+                raise ValueError(f"{cfg_path}: only the RoBERTa-base geometry of ANCE is built (hidden 768, 12 heads, FFN 3072)")
+            if cfg.get("hidden_act", "gelu") != "gelu":
+                raise ValueError(f"{cfg_path}: hidden_act = {cfg['hidden_act']!r}; the kernels implement erf GELU")
+            if cfg.get("position_embedding_type", "absolute") != "absolute":
+                raise ValueError(f"{cfg_path}: position_embedding_type = {cfg['position_embedding_type']!r} is not supported")
+            kw = {"ln_eps": float(cfg.get("layer_norm_eps", 1e-5)), "pad_token_id": int(cfg.get("pad_token_id", 1))}
+        return cls.from_state_dict(sd, device=device, **kw)
 
     # ---- forward -----------------------------------------------------------
     def __call__(self, input_ids, attention_mask, wrap_pooler=False):

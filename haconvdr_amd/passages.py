@@ -187,14 +187,29 @@ def encode_passages(model, passages, out_dir, per_gpu_eval_batch_size=250, n_gpu
     return written
 
 
-def generate_new_ann(args):
-    """Mirror of generate_new_ann(args) (gen_doc_embeddings.py:190-212): args carries the TOML keys of
-    Config/gen_doc_embeddings.toml (pretrained_passage_encoder, tokenized_passage_collection_dir_path,
-    data_output_path, per_gpu_eval_batch_size, n_gpu)."""
+def load_model(model_type, model_path, device=0):
+    """Mirror of load_model(model_type, model_path) (src/models.py:112-140) for the ANCE types: returns
+    ``(tokenizer, model)``.  The tokenizer is the checkpoint's RobertaTokenizer when its vocabulary files are in the
+    directory, else None (the passage pipeline never uses it: it reads pre-tokenized records)."""
     from .encoder import ANCEEncoder
+    if model_type not in ("ANCE_Query", "ANCE_Passage"):
+        raise ValueError("{} is not supported by the MI355X path (ANCE_Query / ANCE_Passage only)".format(model_type))
+    tokenizer = None
+    if os.path.exists(os.path.join(model_path, "vocab.json")) and os.path.exists(os.path.join(model_path, "merges.txt")):
+        from transformers import RobertaTokenizer
+        tokenizer = RobertaTokenizer.from_pretrained(model_path, do_lower_case=True)
+    return tokenizer, ANCEEncoder.from_pretrained(model_path, device=device)
+
+
+def generate_new_ann(args):
+    """Mirror of generate_new_ann(args) (gen_doc_embeddings.py:190-212): ``args`` carries the keys of
+    Config/gen_doc_embeddings.toml (model_type, pretrained_passage_encoder, per_gpu_eval_batch_size, n_gpu,
+    tokenized_passage_collection_dir_path, data_output_path).  The reference wraps the model in nn.DataParallel over
+    ``n_gpu`` devices of one process; here every rank of a torch.distributed launch (RANK / WORLD_SIZE / LOCAL_RANK)
+    encodes the blocks it owns on its own GPU — ``n_gpu`` only sizes the batches and blocks, as there (:73, :88)."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    model = ANCEEncoder.from_pretrained(args.pretrained_passage_encoder, device=local)
+    _, model = load_model(getattr(args, "model_type", "ANCE") + "_Passage", args.pretrained_passage_encoder, device=local)
     passages = TokenizedPassages(os.path.join(args.tokenized_passage_collection_dir_path, "passages"))
     return encode_passages(model, passages, args.data_output_path, args.per_gpu_eval_batch_size, getattr(args, "n_gpu", 1), rank, world)

@@ -14,32 +14,36 @@ import math
 import os
 import pickle
 
+import numpy as np
+
 logger = logging.getLogger(__name__)
 
 
+def _pids_of(offset2pid, offsets):
+    """passage ids of a row of corpus offsets; offset2pid is whatever the pickle held (list, ndarray or dict)."""
+    if isinstance(offset2pid, dict):
+        return [offset2pid[int(o)] for o in offsets]
+    table = offset2pid if isinstance(offset2pid, np.ndarray) else np.asarray(offset2pid)
+    return table[np.asarray(offsets, dtype=np.int64)].tolist()
+
+
 def output_test_res(query_embedding2id, retrieved_scores_mat, retrieved_pid_mat, offset2pid, args, evaluate=None):
-    qids_to_ranked_candidate_passages = {}
-    topN = args.top_k
-    for query_idx in range(len(retrieved_pid_mat)):
-        seen_pid = set()
-        query_id = query_embedding2id[query_idx]
-        selected_ann_idx = retrieved_pid_mat[query_idx][:topN]                    # :238
-        selected_ann_score = retrieved_scores_mat[query_idx][:topN].tolist()      # :239
-        rank = 0
-        if query_id not in qids_to_ranked_candidate_passages:
-            qids_to_ranked_candidate_passages[query_id] = [(0, 0)] * topN         # :244-246
-        for idx, score in zip(selected_ann_idx, selected_ann_score):
-            pred_pid = offset2pid[idx]                                            # :250
-            if pred_pid not in seen_pid:
-                qids_to_ranked_candidate_passages[query_id][rank] = (pred_pid, score)
-                rank += 1
-                seen_pid.add(pred_pid)
+    """TREC run file of a retrieval result (src/test_HAConvDR_topiocqa.py:222-286).  Per query row: the first top_k
+    (offset, score) columns, offsets mapped to passage ids, a passage id kept only where it first occurs; the survivors
+    fill the ranks from 1, the ranks left over read ``0 ... 0``.  A query id met again writes over the head of the list
+    its first occurrence made and inherits the rest.  One line per rank: qid Q0 pid rank 200-rank score ance."""
+    k = args.top_k
+    ranking = {}                                              # qid -> k (pid, score) slots, in first-seen order of the qids
+    for row in range(len(retrieved_pid_mat)):
+        scores = retrieved_scores_mat[row][:k].tolist()       # python floats: their repr is what lands in the file
+        pids = _pids_of(offset2pid, retrieved_pid_mat[row][:k])
+        first = np.sort(np.unique(np.asarray(pids), return_index=True)[1])
+        slots = ranking.setdefault(query_embedding2id[row], [(0, 0)] * k)
+        slots[:len(first)] = [(pids[i], scores[i]) for i in first]
     output_trec_file = os.path.join(args.qrel_output_path, args.output_trec_file)
-    with open(output_trec_file, "w") as g:
-        for qid, passages in qids_to_ranked_candidate_passages.items():
-            for i in range(topN):
-                pid, score = passages[i]
-                g.write(str(qid) + " Q0 " + str(pid) + " " + str(i + 1) + " " + str(-i - 1 + 200) + " " + str(score) + " ance\n")  # :282
+    with open(output_trec_file, "w") as out:
+        out.writelines(f"{qid} Q0 {pid} {rank} {200 - rank} {score} ance\n"
+                       for qid, slots in ranking.items() for rank, (pid, score) in enumerate(slots, start=1))
     logger.info("output file write ok at %s", output_trec_file)
     if evaluate is None:
         if not getattr(args, "trec_gold_qrel_file_path", None):

@@ -84,3 +84,101 @@ def test_encode_then_search_end_to_end(tmp_path):
     e0, _ = read_embedding_block(str(tmp_path), 0)
     D, I = search_one_by_one(argparse.Namespace(passage_block_num=5), str(tmp_path), FlatIPIndex(768), e0[:5], 3)
     assert list(I[:, 0]) == [0, 1, 2, 3, 4]
+
+
+def _checkpoint_dir(path, n_layers=2, **cfg_over):
+    """A HF-style ANCE checkpoint directory: pytorch_model.bin (+ the unused classifier head) and config.json."""
+    import json
+    import torch
+    from haconvdr_amd import synth
+    os.makedirs(path, exist_ok=True)
+    sd = dict(synth.ance_state_dict(0xA11CE, n_layers))
+    sd["classifier.dense.weight"] = np.zeros((768, 768), np.float32)
+    torch.save({k: torch.from_numpy(v) for k, v in sd.items()}, os.path.join(path, "pytorch_model.bin"))
+    cfg = {"architectures": ["RobertaForSequenceClassification"], "model_type": "roberta", "num_hidden_layers": n_layers, "hidden_size": 768,
+           "num_attention_heads": 12, "intermediate_size": 3072, "vocab_size": 50265, "max_position_embeddings": 514, "type_vocab_size": 1,
+           "layer_norm_eps": 1e-05, "pad_token_id": 1, "bos_token_id": 0, "eos_token_id": 2, "hidden_act": "gelu", "finetuning_task": "MSMarco"}
+    cfg.update(cfg_over)
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump(cfg, f)
+    return path
+
+
+@pytest.mark.gpu
+def test_generate_new_ann_then_gen_metric_score_and_save(tmp_path, oracle):
+    """The two entry points a user of the reference runs, end to end on the GPU: generate_new_ann(args) with the keys of
+    Config/gen_doc_embeddings.toml (gen_doc_embeddings.py:190-212) writes the passage blocks — equal to the blocks the
+    REFERENCE's pipeline wrote for the same 23 records — and gen_metric_score_and_save(args, index, Q, ids)
+    (src/test_HAConvDR_topiocqa.py:355-372) searches them and writes the TREC run + metrics."""
+    from types import SimpleNamespace
+    from haconvdr_amd import synth
+    from haconvdr_amd.index import build_index
+    from haconvdr_amd.passages import generate_new_ann, read_embedding_block
+    from haconvdr_amd.trec import gen_metric_score_and_save
+    ckpt = _checkpoint_dir(str(tmp_path / "ad-hoc-ance-msmarco"))
+    tok_dir = tmp_path / "tokenized"
+    os.makedirs(tok_dir)
+    for f in ("passages", "passages_meta"):
+        os.symlink(os.path.join(G, f), tok_dir / f)
+    gen_args = SimpleNamespace(model_type="ANCE", pretrained_passage_encoder=ckpt, max_seq_length=64, per_gpu_eval_batch_size=4, local_rank=-1,
+                               disable_tqdm=True, n_gpu=1, tokenized_passage_collection_dir_path=str(tok_dir), data_output_path=str(tmp_path / "embeds"))
+    assert generate_new_ann(gen_args) == 23
+    e, i = read_embedding_block(gen_args.data_output_path, 0)
+    ref_e = pickle.load(open(os.path.join(G, "passage_emb_block_0.pb"), "rb"))
+    np.testing.assert_array_equal(i, pickle.load(open(os.path.join(G, "passage_embid_block_0.pb"), "rb")))
+    cos = (e * ref_e).sum(1) / (np.linalg.norm(e, axis=1) * np.linalg.norm(ref_e, axis=1))
+    assert np.all(1 - cos < 1e-4)
+    # retrieval over the freshly written blocks
+    offset2pid = [1000 + 3 * (j // 2) for j in range(23)]            # pairs of offsets share a passage id: de-duplication
+    with open(tmp_path / "offset2pid.pickle", "wb") as f:
+        pickle.dump(offset2pid, f)
+    q = synth.embeddings(4242, 6)
+    qids = [f"conv{j // 2}_{j % 2 + 1}" for j in range(6)]
+    with open(tmp_path / "qrels.txt", "w") as f:
+        for j, qid in enumerate(qids):
+            f.write(f"{qid} 0 {offset2pid[(5 * j) % 23]} 1\n")
+    args = SimpleNamespace(n_gpu=1, use_gpu=True, passage_block_num=4, passage_embeddings_dir_path=gen_args.data_output_path, top_k=5,
+                           passage_offset2pid_path=str(tmp_path / "offset2pid.pickle"), qrel_output_path=str(tmp_path), output_trec_file="run.trec",
+                           trec_gold_qrel_file_path=str(tmp_path / "qrels.txt"), rel_threshold=1, test_file_path="unused")
+    res = gen_metric_score_and_save(args, build_index(args), q, qids)
+    assert set(res) == {"MRR", "NDCG@3", "Recall@10", "Recall@100"} and all(0.0 <= v <= 100.0 for v in res.values())
+    lines = open(tmp_path / "run.trec").read().splitlines()
+    assert len(lines) == 6 * 5
+    oD, oI = oracle.flat_ip_search(e, q, 5)                           # exact search over the very rows that were written
+    for j, qid in enumerate(qids):
+        want, seen = [], set()
+        for off, sc in zip(oI[j], oD[j].astype(np.float64).tolist()):
+            if offset2pid[off] not in seen:
+                seen.add(offset2pid[off])
+                want.append((offset2pid[off], sc))
+        want += [(0, 0)] * (5 - len(want))
+        got = [ln.split(" ") for ln in lines[5 * j:5 * j + 5]]
+        assert [g[0] for g in got] == [qid] * 5 and [g[3] for g in got] == list("12345") and [g[4] for g in got] == ["199", "198", "197", "196", "195"]
+        assert [(g[2], g[5]) for g in got] == [(str(p), str(s)) for p, s in want] and all(g[1] == "Q0" and g[6] == "ance" for g in got)
+
+
+@pytest.mark.gpu
+def test_from_pretrained_reads_and_checks_config_json(tmp_path):
+    from haconvdr_amd import synth
+    from haconvdr_amd.encoder import ANCEEncoder
+    from haconvdr_amd.passages import load_model
+    from oracle import ance_oracle
+    ids, lens = synth.token_batch(5, 3, 48, min_len=6)
+    mask = (np.arange(48)[None, :] < lens[:, None]).astype(np.int32)
+    # layer_norm_eps and pad_token_id come from config.json, not from defaults: an unusual eps must change the output
+    # exactly as it changes the fp32 oracle's
+    tok, enc = load_model("ANCE_Query", _checkpoint_dir(str(tmp_path / "a"), layer_norm_eps=1e-2))
+    assert tok is None
+    sd = synth.ance_state_dict(0xA11CE, 2)
+    ref = ance_oracle.ance_forward(sd, ids, mask, eps=1e-2)
+    out = enc(ids, mask)
+    cos = (out * ref).sum(1) / (np.linalg.norm(out, axis=1) * np.linalg.norm(ref, axis=1))
+    assert np.all(1 - cos < 1e-4)
+    plain = ANCEEncoder.from_pretrained(_checkpoint_dir(str(tmp_path / "b")))(ids, mask)
+    assert np.abs(plain - out).max() > 1e-3
+    for bad in (dict(num_hidden_layers=3), dict(intermediate_size=4096), dict(vocab_size=30522), dict(hidden_act="relu"),
+                dict(num_attention_heads=16), dict(max_position_embeddings=512)):
+        with pytest.raises(ValueError):
+            ANCEEncoder.from_pretrained(_checkpoint_dir(str(tmp_path / "c"), **bad))
+    with pytest.raises(ValueError):
+        load_model("BERT_Query", str(tmp_path / "a"))
