@@ -274,6 +274,16 @@ def main():
                        "unit": "GB/s", "frac": round(s_gbs / PEAK_HBM_GBS, 4), "kernel_ms": round(scan_avg_ms, 4)}
     search_roof["traffic"] = pmc("search_hbm_bytes_per_launch") if (world == 1 and rows == CFG3_ROWS) else None
 
+    def mfma_util(needle):
+        """Matrix-pipe busy share etc. of a kernel from the committed rocprofv3 SQ pass (profiles/r02_sq.*), same workload."""
+        u = pmc("mfma_util") or {}
+        for kname, v in u.items():
+            if needle in kname and "short" not in kname:
+                return dict(v, source="profiles/r02_sq.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ... GRBM_GUI_ACTIVE pass of this bench)")
+        return None
+    if world == 1 and rows == CFG3_ROWS:
+        search_roof["mfma_util"] = mfma_util("scanh_kernel<1, false>")
+
     T_tok = nq_loc * Lq                                                   # padded tokens a rank encodes per step
     enc_flops = nq_loc * 12.0 * (14155776.0 * Lq + 4.0 * Lq * Lq * 768.0) + nq_loc * 2.0 * 768 * 768   # SURVEY §8d
     if enc is not None and ffn_up_ms:
@@ -284,9 +294,10 @@ def main():
         avg_ms = float(np.mean(ffn_up_ms))
         tf = fl_launch / (avg_ms * 1e-3) / 1e12
         stack_avg = float(np.sum(stack_ms)) / args.steps
-        roofline = {"kernel": "gemm_bf16_nt_kernel<EPI_GELU> (FFN-up 768->3072, bias + erf-GELU fused)", "bound": "mfma",
+        roofline = {"kernel": "gemm8_kernel<EPI8_GELU> (FFN-up 768->3072: folded LayerNorm + bias + erf-GELU fused)", "bound": "mfma",
                     "achieved": round(tf, 1), "peak": PEAK_F16_MFMA_TF, "unit": "TFLOP/s", "frac": round(tf / PEAK_F16_MFMA_TF, 4),
                     "traffic": pmc("ffn_up_hbm_bytes_per_launch") if world == 1 else None,
+                    "mfma_util": mfma_util("gemm8_kernel<3>") if world == 1 else None,
                     "kernel_ms": round(avg_ms, 4), "launches_per_step": n_launch // args.steps, "flops_per_launch": fl_launch,
                     "share_of_step": round(avg_ms * (n_launch / args.steps) / ms_per_step, 3),
                     "encoder_stack": {"ms_per_step": round(stack_avg, 3), "achieved_TFLOPs": round(enc_flops / (stack_avg * 1e-3) / 1e12, 1),

@@ -1,8 +1,16 @@
 #!/usr/bin/env python3
-"""Copy the summaries of one profiling campaign (gpurun_out/<tag>_{trace,fetch,write}, bench JSON) into
-profiles/r<round>_*: kernel trace/stats, the two PMC passes and the per-launch HBM traffic that bench.py reads.
+"""Turn one profiling campaign (tools/profile_round.sh <tag>, outputs under gpurun_out/<tag>_{trace,fetch,write,sq}) into
+the tracked summaries under profiles/:
 
-  python tools/refresh_profiles.py <tag> <bench.json> [round]
+  python tools/refresh_profiles.py <tag> [bench.json]
+
+  profiles/<tag>_bench.json                 the bench line of an un-profiled run (if given)
+  profiles/<tag>_kernel_trace.{json,md}     per (kernel, grid): calls, avg / median / min / max duration, VGPR / LDS / scratch
+  profiles/<tag>_kernel_stats.csv           rocprofv3's own --stats table
+  profiles/<tag>_pmc_fetch|write.{json,md}  FETCH_SIZE / WRITE_SIZE per launch (KiB; read bytes = KiB x 1024 x 2 on gfx950 for
+                                            16-B/lane streaming reads, write bytes = KiB x 1024: MI355X_MICROARCH.md, HBM)
+  profiles/<tag>_sq.{json,md}               SQ_* / GRBM per launch + derived: matrix-pipe busy share, wave-time split, clock
+  profiles/<tag>_pmc_traffic.json           what bench.py reads back: HBM bytes per launch of the dominant kernels, MFMA busy
 """
 import glob
 import json
@@ -12,45 +20,62 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_SIMD = 256 * 4
 
 
-def pick(js, name, field, tag=None, grid=None):
-    for c in js.get("counters", []):
-        if name in c["kernel"] and (tag is None or tag in c["kernel"]) and (grid is None or c["grid_threads_total"] == grid):
-            return c.get(field)
-    return None
+def rows_of(js, needle):
+    return [c for c in js.get("counters", []) if needle in c["kernel"]]
 
 
 def main():
-    tag, bench = sys.argv[1], sys.argv[2]
-    rnd = sys.argv[3] if len(sys.argv) > 3 else "01"
-    pre = os.path.join(ROOT, "profiles", f"r{rnd}_")
+    tag = sys.argv[1]
+    bench = sys.argv[2] if len(sys.argv) > 2 else None
+    pre = os.path.join(ROOT, "profiles", f"{tag}_")
     summ = os.path.join(ROOT, "tools", "summarize_profile.py")
-    for kind, out in (("trace", "bench_kernel_trace"), ("fetch", "bench_pmc_fetch"), ("write", "bench_pmc_write")):
-        subprocess.run([sys.executable, summ, os.path.join(ROOT, "gpurun_out", f"{tag}_{kind}"), pre + out, "--rows", "1000000", "--nq", "1000"],
-                       check=True, stdout=subprocess.DEVNULL)
-    stats = glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_trace", "*", "*kernel_stats.csv"))
+    for kind, out in (("trace", "kernel_trace"), ("fetch", "pmc_fetch"), ("write", "pmc_write"), ("sq", "sq")):
+        src = os.path.join(ROOT, "gpurun_out", f"{tag}_{kind}")
+        if os.path.isdir(src):
+            subprocess.run([sys.executable, summ, src, pre + out], check=True, stdout=subprocess.DEVNULL)
+    stats = glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_trace", "**", "*kernel_stats.csv"), recursive=True)
     if stats:
-        shutil.copy(stats[0], pre + "bench_kernel_stats.csv")
-    shutil.copy(bench, pre + "bench.json")
-    f = json.load(open(pre + "bench_pmc_fetch.json"))
-    w = json.load(open(pre + "bench_pmc_write.json"))
-    plan = json.load(open(bench))["roofline"]["kernel"]                 # "scanh_kernel<T>"
-    full, seed = plan[:-1] + ", false>", plan[:-1] + ", true>"         # the two instantiations a search launches
-    rl, rs = pick(f, full, "hbm_read_bytes_per_launch"), pick(f, seed, "hbm_read_bytes_per_launch")
-    wl, ws = pick(w, full, "hbm_write_bytes_per_launch"), pick(w, seed, "hbm_write_bytes_per_launch")
-    out = {"rows": 1000000, "nq": 1000,
-           "kernel": plan + " (both launches of one search: maxima-only seeding pass over the first sixteenth of the corpus, then the full pass)",
-           "hbm_read_bytes_per_launch": int(rl + rs), "hbm_write_bytes_per_launch": int(wl + ws), "hbm_bytes_per_launch": int(rl + rs + wl + ws),
-           "per_phase": {"seeding_pass": {"read": int(rs), "write": int(ws)}, "full_pass": {"read": int(rl), "write": int(wl)}},
-           "rescore_kernel": {"hbm_read_bytes_per_launch": int(pick(f, "rescore_kernel", "hbm_read_bytes_per_launch")),
-                              "note": "16-byte gathers from the T64 tiles: one useful piece per 64-B sector; the x2 streaming correction does not apply to gathers, halve this figure"},
-           "exact_kernels": {"kernel": "scanq_kernel<NT=2,W=8>", "hbm_read_bytes_per_launch": int(pick(f, "scanq_kernel<2, 8>", "hbm_read_bytes_per_launch"))},
-           "hbm_regime": {"kernel": "scan16_kernel", "nq": 16, "hbm_read_bytes_per_launch": int(pick(f, "scan16_kernel", "hbm_read_bytes_per_launch", grid=65536)),
-                          "hbm_write_bytes_per_launch": int(pick(w, "scan16_kernel", "hbm_write_bytes_per_launch", grid=65536)), "algorithmic_bytes": 3072068352},
-           "source": f"profiles/r{rnd}_bench_pmc_fetch.json (FETCH_SIZE KiB x 1024 x 2, the gfx950 correction for 16-B/lane streaming reads) + "
-                     f"profiles/r{rnd}_bench_pmc_write.json (WRITE_SIZE KiB x 1024); separate rocprofv3 --pmc passes of "
-                     "`bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-encode`"}
+        shutil.copy(stats[0], pre + "kernel_stats.csv")
+    if bench:
+        shutil.copy(bench, pre + "bench.json")
+    out = {"source": f"profiles/{tag}_pmc_fetch.json, {tag}_pmc_write.json, {tag}_sq.json: separate rocprofv3 --pmc passes of "
+                     "`python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras` (tools/profile_round.sh)"}
+
+    def load(name):
+        p = pre + name + ".json"
+        return json.load(open(p)) if os.path.exists(p) else {}
+    f, w, sq = load("pmc_fetch"), load("pmc_write"), load("sq")
+
+    def traffic(needle, long_runs=False):
+        fr = [c for c in rows_of(f, needle) if (not long_runs or "short" not in c["kernel"])]
+        wr = [c for c in rows_of(w, needle) if (not long_runs or "short" not in c["kernel"])]
+        if not fr or not wr:
+            return None
+        # the instantiation with the largest traffic (the main pass of a kernel that also has a small seeding pass)
+        r = max(c["hbm_read_bytes_per_launch"] for c in fr)
+        ww = max(c["hbm_write_bytes_per_launch"] for c in wr)
+        return {"read": int(r), "write": int(ww), "total": int(r + ww)}
+    t = traffic("gemm8_kernel<3>")
+    if t:
+        out["ffn_up_hbm_bytes_per_launch"] = t["total"]
+        out["ffn_up"] = t
+    t = traffic("scanh_kernel<1, false>")
+    if t:
+        out["search_hbm_bytes_per_launch"] = t["total"]
+        out["search"] = t
+    for name, needle in (("qk", "gemm8_kernel<0>"), ("v", "gemm8_kernel<1>"), ("resid", "gemm8_kernel<2>"), ("attention", "attention_kernel<8>"),
+                         ("rescore", "rescore_kernel")):
+        t = traffic(needle)
+        if t:
+            out[name] = t
+    util = {}
+    for c in sq.get("counters", []):
+        if "mfma_busy_share" in c:
+            util[c["kernel"]] = {k: c[k] for k in ("mfma_busy_share", "clock_GHz", "wave_parked", "wave_issue_stalled", "wave_issuing") if k in c}
+    out["mfma_util"] = util
     json.dump(out, open(pre + "pmc_traffic.json", "w"), indent=1)
     print(json.dumps(out, indent=1))
 

@@ -81,12 +81,14 @@ def main():
                 dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
                 rows.append((key, r["Counter_Name"], float(r["Counter_Value"]), dur))
                 durs[key].append(dur)
+        agg_dur = defaultdict(list)
         for key, name, val, dur in rows:
             lo, hi = min(durs[key]), max(durs[key])
             tag = ""
             if lo > 0 and hi > 4 * lo:
                 tag = " [short runs]" if dur < (lo * hi) ** 0.5 else " [long runs]"
             agg[(key[0] + tag, key[1], key[2])][name].append(val)
+            agg_dur[(key[0] + tag, key[1], key[2])].append(dur)
         out["counters"] = []
         for key, cs in agg.items():
             row = {"kernel": key[0], "grid_threads_total": int(key[1]), "block": int(key[2])}
@@ -97,6 +99,23 @@ def main():
                 row["hbm_read_bytes_per_launch"] = row["FETCH_SIZE_avg"] * 1024 * 2
             if "WRITE_SIZE" in cs:
                 row["hbm_write_bytes_per_launch"] = row["WRITE_SIZE_avg"] * 1024
+            if "GRBM_GUI_ACTIVE" in cs:
+                # GRBM_GUI_ACTIVE is summed over the 8 XCDs: / 8 = kernel cycles; the SQ counters are summed over the chip's
+                # 1024 SIMDs; SQ_VALU_MFMA_BUSY_CYCLES counts cycles, SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* quad-cycles
+                # (MI355X_MICROARCH.md, cycle constants)
+                cyc = row["GRBM_GUI_ACTIVE_avg"] / 8.0
+                row["kernel_cycles"] = cyc
+                d_us = sum(agg_dur[key]) / len(agg_dur[key])
+                row["avg_us_under_pmc"] = round(d_us, 2)
+                if d_us > 0:
+                    row["clock_GHz"] = round(cyc / d_us / 1e3, 3)
+                if "SQ_VALU_MFMA_BUSY_CYCLES" in cs and cyc > 0:
+                    row["mfma_busy_share"] = round(row["SQ_VALU_MFMA_BUSY_CYCLES_avg"] / (cyc * 1024.0), 4)
+                if "SQ_WAVE_CYCLES" in cs and row["SQ_WAVE_CYCLES_avg"] > 0:
+                    wv = row["SQ_WAVE_CYCLES_avg"]
+                    for src, dst in (("SQ_WAIT_ANY", "wave_parked"), ("SQ_WAIT_INST_ANY", "wave_issue_stalled"), ("SQ_ACTIVE_INST_ANY", "wave_issuing")):
+                        if src in cs:
+                            row[dst] = round(row[src + "_avg"] / wv, 4)
             out["counters"].append(row)
     json.dump(out, open(prefix + ".json", "w"), indent=1)
     with open(prefix + ".md", "w") as f:
