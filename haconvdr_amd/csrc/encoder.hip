@@ -1046,7 +1046,6 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
         g.total_rows = total;
         Gemm8Args g8a{};
         g8a.total_rows = total;
-        g8a.skew_ticks = 100;   // 1 us between the XCDs' starts (measured: 0 -> 100 ticks: FFN-up -9 %, out-proj -9 %; 200-400 the same, 800 worse)
         const dim3 grid8((unsigned)e->n_cu), blk8(512);
         const size_t lds8 = 131072;
         // QKV

@@ -154,3 +154,25 @@ def test_bench_starts_its_own_ranks():
     assert len({l.split()[-1] for l in lines}) == 1           # one rendezvous port for all ranks
     bad = subprocess.run(cmd + ["7"], capture_output=True, text=True, timeout=120)
     assert bad.returncode == 7
+
+
+def test_large_batch_gemm_kernels_keep_everything_in_registers():
+    """gemm8_kernel's k-loop keeps an LDS-DMA stream in flight behind counted waits.  A register spill would add scratch
+    loads to that stream, and hipcc drains the whole queue (vmcnt(0)) for each of them: measured at half the k-loop rate.
+    The build keeps hipcc's resource report (csrc/Makefile); every instantiation must show no spill and no scratch."""
+    path = os.path.join(ROOT, "haconvdr_amd", "csrc", "encoder.resources.txt")
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(path)])
+    text = open(path).read()
+    blocks = re.split(r"remark: Function Name: ", text)
+    seen = 0
+    for b in blocks:
+        if "gemm8_kernel" not in b.split("\n", 1)[0]:
+            continue
+        seen += 1
+        vgpr = int(re.search(r"VGPRs: (\d+)", b).group(1))
+        assert vgpr <= 256
+        assert int(re.search(r"VGPRs Spill: (\d+)", b).group(1)) == 0, b[:200]
+        assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1)) == 0, b[:200]
+        assert int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1)) == 2
+    assert seen == 4

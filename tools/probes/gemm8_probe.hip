@@ -1,0 +1,51 @@
+// Probe of the large-batch GEMM (haconvdr_amd/csrc/gemm8.inc) on the encoder's five shapes at M = 131072: timing, and with
+// -DG8_STAMP in-kernel s_memtime stamps around the tile boundary (epilogue, first k-tiles); -DG8_NO_EPI times the k-loop alone.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 [-DG8_STAMP] [-DG8_NO_EPI] tools/probes/gemm8_probe.hip -o gemm8_probe
+#include "../../haconvdr_amd/csrc/encoder.hip"
+#include <cstdio>
+#include <vector>
+#include <random>
+#define CK(x) do{hipError_t e_=(x); if(e_!=hipSuccess){printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} }while(0)
+using namespace hac;
+template <int EPI> float run(Gemm8Args g, int iters){
+  CK(hipFuncSetAttribute((const void*)gemm8_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+  hipEvent_t e0,e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for(int i=0;i<2;i++) gemm8_kernel<EPI><<<256,512,131072>>>(g);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for(int i=0;i<iters;i++) gemm8_kernel<EPI><<<256,512,131072>>>(g);
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms,e0,e1)); return ms/iters;
+}
+int main(){
+  const int M = 131072;
+  std::mt19937 rng(1); std::normal_distribution<float> nd(0.f,1.f);
+  auto mk = [&](size_t n, float sc){ std::vector<float> h(n); for(auto&v:h) v=nd(rng)*sc; float* d; CK(hipMalloc(&d,n*4)); CK(hipMemcpy(d,h.data(),n*4,hipMemcpyHostToDevice)); bf16* b; CK(hipMalloc(&b,n*2)); f32_to_bf16_kernel<<<(n+255)/256,256>>>(d,b,n); CK(hipDeviceSynchronize()); CK(hipFree(d)); return b; };
+  const size_t poolA = (size_t)8192*3072;
+  bf16* Apool = mk(poolA, 1.0f);
+  bf16* A; CK(hipMalloc(&A,(size_t)M*3072*2));
+  for(size_t off=0; off<(size_t)M*3072; off+=poolA) CK(hipMemcpy(A+off, Apool, std::min(poolA,(size_t)M*3072-off)*2, hipMemcpyDeviceToDevice));
+  bf16* W = mk((size_t)3072*3072, 0.02f);
+  float* vec; CK(hipMalloc(&vec, 3072*4*4)); CK(hipMemset(vec,0,3072*16));
+  int* total; CK(hipMalloc(&total,4)); CK(hipMemcpy(total,&M,4,hipMemcpyHostToDevice));
+  bf16 *q,*k,*vt,*h,*yb,*yb2; float *y,*resid; float2 *stats,*part;
+  CK(hipMalloc(&q,(size_t)M*768*2)); CK(hipMalloc(&k,(size_t)M*768*2)); CK(hipMalloc(&vt,(size_t)768*(M+64)*2)); CK(hipMalloc(&h,(size_t)M*3072*2)); CK(hipMalloc(&yb,(size_t)M*768*2)); CK(hipMalloc(&yb2,(size_t)M*768*2)); CK(hipMemset(yb2,0,(size_t)M*768*2));
+  CK(hipMalloc(&y,(size_t)M*768*4)); CK(hipMalloc(&resid,(size_t)M*768*4)); CK(hipMemset(resid,0,(size_t)M*768*4));
+  CK(hipMalloc(&stats,(size_t)M*8)); CK(hipMalloc(&part,(size_t)M*12*8));
+  fill_identity_stats_kernel<<<(M+255)/256,256>>>(stats,(size_t)M); CK(hipDeviceSynchronize());
+  Gemm8Args g{}; g.A=A; g.W=W; g.total_rows=total; g.astats=stats; g.wsum=vec; g.cvec=vec+3072; g.q=q; g.k=k; g.v16=vt; g.resid=yb2; g.rstats=stats; g.rgamma=vec+6144; g.rbeta=vec+9216; g.yb=yb; g.part=part; g.h=h;
+  struct Cfg{const char* name; int N,K,epi;};
+  Cfg cfgs[] = {{"QK    N=1536 K=768 ",1536,768,EPI8_QK},{"V     N=768  K=768 ",768,768,EPI8_V},{"OUT   N=768  K=768 ",768,768,EPI8_RESID},{"FFN1  N=3072 K=768 ",3072,768,EPI8_GELU},{"FFN2  N=768  K=3072",768,3072,EPI8_RESID}};
+  for(auto&c: cfgs){
+    g.N=c.N; g.K=c.K; float t=0;
+    if(c.epi==EPI8_QK) t=run<EPI8_QK>(g,5); if(c.epi==EPI8_V) t=run<EPI8_V>(g,5); if(c.epi==EPI8_RESID) t=run<EPI8_RESID>(g,5); if(c.epi==EPI8_GELU) t=run<EPI8_GELU>(g,5);
+    printf("%s : %.3f ms %.0f TF\n", c.name, t, 2.0*M*c.N*c.K/t/1e9);
+#ifdef G8_STAMP
+    { unsigned long long hs[64]; CK(hipMemcpy(hs, part, sizeof hs, hipMemcpyDeviceToHost));
+      for (int gq = 0; gq < 2; ++gq) { unsigned long long* h = hs + gq*16; if (h[10]) printf("   group %d RESID epilogue: loads issued %llu | band0 wait+compute %llu | band1 load+compute %llu | stores issued %llu\n", gq, h[10]-h[1], h[11]-h[10], h[12]-h[11], h[13]-h[12]); printf("   group %d: kloop-end->aligned %llu | +2 stages & drain %llu | epilogue issue %llu | ->k0 barrier %llu | k0->k1 %llu | k1->k2 %llu | k2->k3 %llu\n", gq,
+        h[0]-h[8], h[1]-h[0], h[2]-h[1], h[3]-h[2], h[4]-h[3], h[5]-h[4], h[6]-h[5]); } }
+#endif
+  }
+  return 0;
+}
+namespace hac { std::string &last_error_slot(){ static std::string s; return s; } int fail(int code, const char *fmt, ...){ (void)fmt; return code; } }

@@ -2,7 +2,10 @@
 """Turn one profiling campaign (tools/profile_round.sh <tag>, outputs under gpurun_out/<tag>_{trace,fetch,write,sq}) into
 the tracked summaries under profiles/:
 
-  python tools/refresh_profiles.py <tag> [bench.json]
+  python tools/refresh_profiles.py <tag> [--raw DIR] [--out DIR] [--bench bench.json]
+
+(on the GPU box profile_round.sh runs it with --raw /tmp/hac_prof --out gpurun_out/<tag>_profiles; the files that come
+back are then copied into profiles/)
 
   profiles/<tag>_bench.json                 the bench line of an un-profiled run (if given)
   profiles/<tag>_kernel_trace.{json,md}     per (kernel, grid): calls, avg / median / min / max duration, VGPR / LDS / scratch
@@ -29,14 +32,18 @@ def rows_of(js, needle):
 
 def main():
     tag = sys.argv[1]
-    bench = sys.argv[2] if len(sys.argv) > 2 else None
-    pre = os.path.join(ROOT, "profiles", f"{tag}_")
+    opts = dict(zip(sys.argv[2::2], sys.argv[3::2]))
+    raw = opts.get("--raw", os.path.join(ROOT, "gpurun_out"))
+    outdir = opts.get("--out", os.path.join(ROOT, "profiles"))
+    bench = opts.get("--bench")
+    os.makedirs(outdir, exist_ok=True)
+    pre = os.path.join(outdir, f"{tag}_")
     summ = os.path.join(ROOT, "tools", "summarize_profile.py")
     for kind, out in (("trace", "kernel_trace"), ("fetch", "pmc_fetch"), ("write", "pmc_write"), ("sq", "sq")):
-        src = os.path.join(ROOT, "gpurun_out", f"{tag}_{kind}")
+        src = os.path.join(raw, f"{tag}_{kind}")
         if os.path.isdir(src):
             subprocess.run([sys.executable, summ, src, pre + out], check=True, stdout=subprocess.DEVNULL)
-    stats = glob.glob(os.path.join(ROOT, "gpurun_out", f"{tag}_trace", "**", "*kernel_stats.csv"), recursive=True)
+    stats = glob.glob(os.path.join(raw, f"{tag}_trace", "**", "*kernel_stats.csv"), recursive=True)
     if stats:
         shutil.copy(stats[0], pre + "kernel_stats.csv")
     if bench:
