@@ -1053,10 +1053,8 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
             // A = the previous layer's un-normalized output rows (bf16) + their statistics; layer 0: the normalized embedding rows
             HAC_TRY(prof_begin(e, 1 + HAC_ENC_CLASS_QKV, st));
             g8a.A = xb; g8a.K = H; g8a.astats = li ? statsF : idstats;
-            g8a.W = w.wqkv8; g8a.N = 2 * H; g8a.wsum = w.fold; g8a.cvec = w.fold + 3 * H; g8a.q = q; g8a.k = k;
-            gemm8_kernel<EPI8_QK><<<grid8, blk8, lds8, st>>>(g8a);
-            g8a.W = w.wqkv8 + (size_t)2 * H * H; g8a.N = H; g8a.wsum = w.fold + 2 * H; g8a.cvec = w.fold + 5 * H; g8a.v16 = vt;
-            gemm8_kernel<EPI8_V><<<grid8, blk8, lds8, st>>>(g8a);
+            g8a.W = w.wqkv8; g8a.N = 3 * H; g8a.wsum = w.fold; g8a.cvec = w.fold + 3 * H; g8a.q = q; g8a.k = k; g8a.v16 = vt;
+            gemm8_kernel<EPI8_QKV><<<grid8, blk8, lds8, st>>>(g8a);
             HAC_TRY(prof_end(e, 1 + HAC_ENC_CLASS_QKV, st));
         } else {
             g.A = xb; g.W = w.wqkv; g.bias = w.bqkv; g.N = 3 * H; g.K = H; g.q = q; g.k = k; g.v16 = vt;
@@ -1208,8 +1206,7 @@ int hac_encoder_create(const hac_encoder_config *cfg, int device, hac_encoder **
     (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_QKV, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
     (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_RESID, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
     (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_GELU, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-    (void)hipFuncSetAttribute((const void *)gemm8_kernel<EPI8_QK>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    (void)hipFuncSetAttribute((const void *)gemm8_kernel<EPI8_V>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void *)gemm8_kernel<EPI8_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void *)gemm8_kernel<EPI8_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void *)gemm8_kernel<EPI8_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     if (const char *m = getenv("HAC_ENC_GEMM")) e->gemm_mode = m[0] == 'c' ? 0 : (m[0] == '8' ? 1 : -1);   // classic | 8phase | auto

@@ -35,10 +35,10 @@ int main(){
   fill_identity_stats_kernel<<<(M+255)/256,256>>>(stats,(size_t)M); CK(hipDeviceSynchronize());
   Gemm8Args g{}; g.A=A; g.W=W; g.total_rows=total; g.astats=stats; g.wsum=vec; g.cvec=vec+3072; g.q=q; g.k=k; g.v16=vt; g.resid=yb2; g.rstats=stats; g.rgamma=vec+6144; g.rbeta=vec+9216; g.yb=yb; g.part=part; g.h=h;
   struct Cfg{const char* name; int N,K,epi;};
-  Cfg cfgs[] = {{"QK    N=1536 K=768 ",1536,768,EPI8_QK},{"V     N=768  K=768 ",768,768,EPI8_V},{"OUT   N=768  K=768 ",768,768,EPI8_RESID},{"FFN1  N=3072 K=768 ",3072,768,EPI8_GELU},{"FFN2  N=768  K=3072",768,3072,EPI8_RESID}};
+  Cfg cfgs[] = {{"QKV   N=2304 K=768 ",2304,768,EPI8_QKV},{"OUT   N=768  K=768 ",768,768,EPI8_RESID},{"FFN1  N=3072 K=768 ",3072,768,EPI8_GELU},{"FFN2  N=768  K=3072",768,3072,EPI8_RESID}};
   for(auto&c: cfgs){
     g.N=c.N; g.K=c.K; float t=0;
-    if(c.epi==EPI8_QK) t=run<EPI8_QK>(g,5); if(c.epi==EPI8_V) t=run<EPI8_V>(g,5); if(c.epi==EPI8_RESID) t=run<EPI8_RESID>(g,5); if(c.epi==EPI8_GELU) t=run<EPI8_GELU>(g,5);
+    if(c.epi==EPI8_QKV) t=run<EPI8_QKV>(g,5); if(c.epi==EPI8_RESID) t=run<EPI8_RESID>(g,5); if(c.epi==EPI8_GELU) t=run<EPI8_GELU>(g,5);
     printf("%s : %.3f ms %.0f TF\n", c.name, t, 2.0*M*c.N*c.K/t/1e9);
 #ifdef G8_STAMP
     { unsigned long long hs[64]; CK(hipMemcpy(hs, part, sizeof hs, hipMemcpyDeviceToHost));
