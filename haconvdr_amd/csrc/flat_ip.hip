@@ -61,9 +61,9 @@ constexpr size_t LDS_LIMIT = 160 * 1024;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct SegDesc {
-    const float4 *ptr;  // tiled rows of this segment
+    const float4 *ptr;  // tiled rows of this segment (T64, fp32)
     u32 gstart;         // first global group index of this segment
-    u32 pad;
+    u32 hoff64;         // the segment's fp16 image (H64, scan_split.inc) starts hoff64 * 64 bytes behind ptr
 };
 
 // ------------------------------------------------------------------ key packing
@@ -142,13 +142,21 @@ __device__ void block_sort_desc(u64 *buf, u32 n, int tid, int nthreads) {
 // Row-major rows -> T64 tiles.  One workgroup per destination group touched by
 // segment rows [row0, row0 + m).  Reads are row-contiguous (256 B per 16 lanes),
 // writes are whole 1-KiB chunks; the transpose goes through a padded LDS tile.
+//
+// The same pass writes the half-precision image the many-query prefilter streams ("H64", fp16 = round-to-nearest-even
+// of every element): a group is K4/4 steps of 2 KiB; step t holds, for row 32*hf + r and k = 16t + 8hh .. +8, eight
+// fp16 at byte t*2048 + hf*1024 + hh*512 + r*16 -- one KiB per (step, row half) is one LDS-DMA instruction of
+// scanh_kernel and, lane for lane, the A operand of v_mfma_f32_32x32x16_f16.  +50 % of HBM for the corpus; the exact
+// kernels and the rescoring read only the fp32 tiles.
 __global__ __launch_bounds__(256) void tile_rows_kernel(const float4 *__restrict__ src, long m, int K4,
-                                                        float4 *__restrict__ seg, long row0, u32 *__restrict__ norm2_max_bits) {
+                                                        float4 *__restrict__ seg, uint4 *__restrict__ hseg, long row0,
+                                                        u32 *__restrict__ norm2_max_bits) {
     __shared__ float4 tile[16][65];
     const int tid = threadIdx.x;
     const long gd = row0 / GROUP_ROWS + blockIdx.x;
     const long r_lo = max(row0, gd * GROUP_ROWS), r_hi = min(row0 + m, gd * GROUP_ROWS + GROUP_ROWS);
     float4 *dst = seg + gd * (long)K4 * GROUP_ROWS;
+    uint4 *hdst = hseg + gd * (long)K4 * (GROUP_ROWS / 2);   // 16-byte pieces: K4 * 512 bytes per group
     // |x|^2 of the rows passing through (thread = 4 rows x one of 16 column lanes): the largest row norm of
     // the index is the scale of the half-precision prefilter's error bound (scan_split.inc)
     float ss[4] = {0.f, 0.f, 0.f, 0.f};
@@ -168,6 +176,19 @@ __global__ __launch_bounds__(256) void tile_rows_kernel(const float4 *__restrict
             const int c = i >> 6, r = i & 63;
             const long dr = gd * GROUP_ROWS + r;
             if (dr >= r_lo && dr < r_hi && k4b + c < K4) dst[(long)(k4b + c) * GROUP_ROWS + r] = tile[c][r];
+        }
+        // fp16 image: the 16 chunks are 4 steps; piece pid = (step, hf, hh, r) holds chunks 4*step + 2*hh, +1 of row 32*hf + r
+        for (int pid = tid; pid < 512; pid += 256) {
+            const int tl = pid >> 7, hf = (pid >> 6) & 1, hh = (pid >> 5) & 1, r = 32 * hf + (pid & 31), c0 = 4 * tl + 2 * hh;
+            const long dr = gd * GROUP_ROWS + r;
+            if (dr >= r_lo && dr < r_hi && k4b + c0 < K4) {
+                const float4 a = tile[c0][r], b = tile[c0 + 1][r];
+                typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+                h8 h;
+                h[0] = (_Float16)a.x; h[1] = (_Float16)a.y; h[2] = (_Float16)a.z; h[3] = (_Float16)a.w;
+                h[4] = (_Float16)b.x; h[5] = (_Float16)b.y; h[6] = (_Float16)b.z; h[7] = (_Float16)b.w;
+                hdst[(long)((k4b >> 2) + tl) * 128 + (pid & 127)] = __builtin_bit_cast(uint4, h);
+            }
         }
         __syncthreads();
     }
@@ -820,9 +841,10 @@ u32 next_pow2(u32 v) {
 
 // ------------------------------------------------------------------ one-device index
 struct Segment {
-    float4 *buf = nullptr;
-    int64_t cap_rows = 0;  // multiple of 64
+    float4 *buf = nullptr;   // one allocation: cap_rows * d fp32 (T64 tiles), then cap_rows * d fp16 (H64 image)
+    int64_t cap_rows = 0;    // multiple of 64
     int64_t rows = 0;
+    uint4 *himg(int d) const { return reinterpret_cast<uint4 *>(reinterpret_cast<char *>(buf) + (size_t)cap_rows * d * 4); }
 };
 
 struct DeviceIndex {
@@ -994,11 +1016,13 @@ struct DeviceIndex {
         Segment s;
         s.cap_rows = (rows_needed + GROUP_ROWS - 1) / GROUP_ROWS * GROUP_ROWS;
         const size_t bytes = (size_t)s.cap_rows * d * sizeof(float);
-        hipError_t e = hipMalloc((void **)&s.buf, bytes);
-        if (e != hipSuccess) return fail(HAC_ERR_OOM, "hipMalloc(%zu) for %lld rows failed: %s", bytes, (long long)rows_needed, hipGetErrorString(e));
-        // zero the last group so that padding rows are finite
+        if ((bytes >> 6) > 0xFFFFFFFFull) return fail(HAC_ERR_UNSUPPORTED, "a single add() of %lld rows exceeds the segment size limit (256 GiB of fp32 rows)", (long long)rows_needed);
+        hipError_t e = hipMalloc((void **)&s.buf, bytes + bytes / 2);   // fp32 tiles + fp16 image
+        if (e != hipSuccess) return fail(HAC_ERR_OOM, "hipMalloc(%zu) for %lld rows failed: %s", bytes + bytes / 2, (long long)rows_needed, hipGetErrorString(e));
+        // zero the last group of both images so that padding rows are finite
         const size_t gbytes = (size_t)GROUP_ROWS * d * sizeof(float);
         HAC_HIP(hipMemsetAsync((char *)s.buf + bytes - gbytes, 0, gbytes, st));
+        HAC_HIP(hipMemsetAsync((char *)s.buf + bytes + bytes / 2 - gbytes / 2, 0, gbytes / 2, st));
         segs.push_back(s);
         return HAC_OK;
     }
@@ -1009,11 +1033,14 @@ struct DeviceIndex {
         for (auto &s : segs) total_cap += (s.rows + GROUP_ROWS - 1) / GROUP_ROWS * GROUP_ROWS;
         Segment big;
         big.cap_rows = total_cap;
-        HAC_HIP(hipMalloc((void **)&big.buf, (size_t)total_cap * d * sizeof(float)));
+        HAC_HIP(hipMalloc((void **)&big.buf, (size_t)total_cap * d * 6));
         int64_t off_rows = 0;
         for (auto &s : segs) {
             const int64_t gr = (s.rows + GROUP_ROWS - 1) / GROUP_ROWS * GROUP_ROWS;
-            if (gr) HAC_HIP(hipMemcpyAsync((char *)big.buf + (size_t)off_rows * d * 4, s.buf, (size_t)gr * d * 4, hipMemcpyDeviceToDevice, st));
+            if (gr) {
+                HAC_HIP(hipMemcpyAsync((char *)big.buf + (size_t)off_rows * d * 4, s.buf, (size_t)gr * d * 4, hipMemcpyDeviceToDevice, st));
+                HAC_HIP(hipMemcpyAsync((char *)big.himg(d) + (size_t)off_rows * d * 2, s.himg(d), (size_t)gr * d * 2, hipMemcpyDeviceToDevice, st));
+            }
             off_rows += gr;
             big.rows += s.rows;
         }
@@ -1041,7 +1068,7 @@ struct DeviceIndex {
             const long row0 = (long)s.rows;
             const long g_lo = row0 / GROUP_ROWS, g_hi = (row0 + m + GROUP_ROWS - 1) / GROUP_ROWS;
             tile_rows_kernel<<<dim3((unsigned)(g_hi - g_lo)), dim3(256), 0, st>>>(
-                reinterpret_cast<const float4 *>(src_dev + (size_t)done * d), (long)m, K4, s.buf, row0, (u32 *)ws_norm.p);
+                reinterpret_cast<const float4 *>(src_dev + (size_t)done * d), (long)m, K4, s.buf, s.himg(d), row0, (u32 *)ws_norm.p);
             HAC_HIP(hipGetLastError());
             s.rows += m;
             done += m;
@@ -1108,7 +1135,7 @@ struct DeviceIndex {
             if (s.rows == 0) continue;
             h[n].ptr = s.buf;
             h[n].gstart = g;
-            h[n].pad = 0;
+            h[n].hoff64 = (u32)(((size_t)s.cap_rows * d * 4) >> 6);
             g += (u32)((s.rows + GROUP_ROWS - 1) / GROUP_ROWS);
             ++n;
         }
@@ -1312,9 +1339,9 @@ struct DeviceIndex {
     static constexpr int SPLIT_K2 = 256, SPLIT_C2 = 512;
     bool split_eligible(int64_t nq, int k) const {
         if (tune.split == 0) return false;   // 0: never, 1: whenever supported (tests), -1: by size
-        // d % 64 == 0 (whole query slices) and at least 8 k-steps per row: the corpus ring runs 6 steps ahead and
+        // d % 64 == 0 (whole query slices) and at least 12 k-steps per row: the corpus ring runs up to 9 steps ahead and
         // may reach into the NEXT group only
-        if (K4 % 16 != 0 || K4 < 32 || d > HAC_MAX_D || k > SPLIT_K2 - 64 || ntotal < SPLIT_K2) return false;
+        if (K4 % 16 != 0 || K4 < 48 || d > HAC_MAX_D || k > SPLIT_K2 - 64 || ntotal < SPLIT_K2) return false;
         if (tune.split == 1) return true;
         return nq >= 48 && (double)nq * (double)ntotal >= 1.0e8;
     }

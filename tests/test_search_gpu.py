@@ -618,9 +618,9 @@ def test_split_prefilter_cascade_escalates_to_three_products(oracle, monkeypatch
     assert_same(D, I, *oracle.flat_ip_search(x, q, 100))
 
 
-@pytest.mark.parametrize("d", [64, 128, 512, 1024])
+@pytest.mark.parametrize("d", [64, 128, 192, 512, 1024])
 def test_split_prefilter_other_dimensions(d, oracle, monkeypatch):
-    """The prefilter is generic in d (multiples of 64 from 128 up to HAC_MAX_D): same answers as the exact kernels
+    """The prefilter is generic in d (multiples of 64 from 192 up to HAC_MAX_D): same answers as the exact kernels
     and the oracle; clustered rows (many near-ties) exercise the cascade on the way."""
     from haconvdr_amd.index import FlatIPIndex
     rng = np.random.default_rng(1000 + d)
@@ -633,7 +633,7 @@ def test_split_prefilter_other_dimensions(d, oracle, monkeypatch):
     D0, I0 = idx.search(q, 50)
     idx.set_option("split", "1")
     D1, I1 = idx.search(q, 50)
-    if d >= 128:
+    if d >= 192:
         assert idx.last_plan().startswith("split:"), idx.last_plan()
         assert _plan_fields(idx)[2] <= 1.0, idx.last_plan()    # the proven bound held on every rescored candidate
     else:
@@ -710,7 +710,7 @@ def test_split_prefilter_randomized_differential(monkeypatch):
     from haconvdr_amd.index import FlatIPIndex
     rng = np.random.default_rng(20260101)
     for case in range(14):
-        d = int(rng.choice([128, 256, 512, 768, 1024]))
+        d = int(rng.choice([192, 256, 512, 768, 1024]))
         n = int(rng.integers(300, 60000))
         nq = int(rng.integers(48, 400))
         k = int(rng.integers(1, 193))
