@@ -33,7 +33,7 @@ int main(){
   CK(hipMalloc(&y,(size_t)M*768*4)); CK(hipMalloc(&resid,(size_t)M*768*4)); CK(hipMemset(resid,0,(size_t)M*768*4));
   CK(hipMalloc(&stats,(size_t)M*8)); CK(hipMalloc(&part,(size_t)M*12*8));
   fill_identity_stats_kernel<<<(M+255)/256,256>>>(stats,(size_t)M); CK(hipDeviceSynchronize());
-  Gemm8Args g{}; g.A=A; g.W=W; g.total_rows=total; g.astats=stats; g.wsum=vec; g.cvec=vec+3072; g.q=q; g.k=k; g.v16=vt; g.resid=yb2; g.rstats=stats; g.rgamma=vec+6144; g.rbeta=vec+9216; g.yb=yb; g.part=part; g.h=h;
+  Gemm8Args g{}; g.n_groups=1; g.A=A; g.W=W; g.total_rows=total; g.astats=stats; g.wsum=vec; g.cvec=vec+3072; g.q=q; g.k=k; g.v16=vt; g.resid=yb2; g.rstats=stats; g.rgamma=vec+6144; g.rbeta=vec+9216; g.yb=yb; g.part=part; g.h=h;
   struct Cfg{const char* name; int N,K,epi;};
   Cfg cfgs[] = {{"QKV   N=2304 K=768 ",2304,768,EPI8_QKV},{"OUT   N=768  K=768 ",768,768,EPI8_RESID},{"FFN1  N=3072 K=768 ",3072,768,EPI8_GELU},{"FFN2  N=768  K=3072",768,3072,EPI8_RESID}};
   for(auto&c: cfgs){
