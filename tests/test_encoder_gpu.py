@@ -88,6 +88,26 @@ def test_large_batch_kernels_agree_with_classic_on_every_row_and_are_determinist
     np.testing.assert_array_equal(outs[0], outs[2])
 
 
+@pytest.mark.parametrize("n_seq", [1, 2, 3, 5, 7, 13, 29, 64])
+def test_large_batch_kernels_tile_coverage(n_seq):
+    """The persistent tile runs of the ping-pong GEMM (XCD shares of the row tiles, column groups for FFN-up) must cover
+    every output tile exactly once for any number of row tiles: batches of 2 .. 128 row tiles, every embedding against the
+    classic kernels (a skipped or doubled tile shows as a wrong row)."""
+    from haconvdr_amd import synth
+    enc = encoder(2)
+    ids, lens = synth.token_batch(100 + n_seq, n_seq, 512, min_len=400)
+    mask = (np.arange(512)[None, :] < lens[:, None]).astype(np.int32)
+    enc.set_option("gemm", "classic")
+    ref = enc(ids, mask)
+    enc.set_option("gemm", "8phase")
+    try:
+        out = enc(ids, mask)
+    finally:
+        enc.set_option("gemm", "auto")
+    assert np.isfinite(out).all()
+    assert one_minus_cos(out, ref).max() < 1e-4
+
+
 def test_encoder_vs_oracle_one_layer():
     """1-layer model: errors cannot hide behind 12 layers of averaging."""
     from haconvdr_amd import synth
