@@ -383,6 +383,25 @@ def main():
             del idx2, srch2
         if world == 1:
             extras.update(single_gpu_extras(np, torch, synth, FlatIPIndex, enc, index, q_pre, dev, n_local, nq, k, sync))
+        elif enc is not None:
+            # BASELINE configs[4] shape on N GPUs: passage encoding is embarrassingly parallel (every rank encodes the blocks it
+            # owns, no collective): each rank times 1000 synthetic passages of L = 384, the job rate is the sum over ranks
+            Bp, Lp = 1000, 384
+            ptok, _ = synth.token_batch(0xD0C + rank, Bp, Lp, fixed_len=Lp)
+            plens = np.clip(np.rint(180.0 + 80.0 * synth.normal(0x1E45 + rank, (Bp,))), 8, Lp).astype(np.int64)
+            pid_t = torch.from_numpy(ptok.astype(np.int64)).to(dev)
+            masks = {"padded": torch.ones_like(pid_t),
+                     "varlen": (torch.arange(Lp, device=dev)[None, :] < torch.from_numpy(plens).to(dev)[:, None]).to(torch.int64)}
+            psg = {"batch_per_gpu": Bp, "gpus": world}
+            for name, m in masks.items():
+                rate = torch.tensor([Bp / timed(lambda: enc(pid_t, m), 3, sync, barrier)], device=dev, dtype=torch.float64)
+                lo_rate = rate.clone()
+                dist.all_reduce(rate, op=dist.ReduceOp.SUM)
+                dist.all_reduce(lo_rate, op=dist.ReduceOp.MIN)
+                psg[f"docs_per_sec_{name}"] = round(float(rate.item()), 1)
+                psg[f"docs_per_sec_per_gpu_{name}_min"] = round(float(lo_rate.item()), 1)
+            psg["mfma_bf16_frac_padded"] = round(12.0 * (14155776.0 * Lp + 4.0 * Lp * Lp * 768.0) * psg["docs_per_sec_padded"] / world / 2.5e15, 4)
+            extras["passages_L384"] = psg
 
     if rank == 0:
         out.update(extras)
