@@ -6,8 +6,8 @@ Writes the same TREC run file, line for line: ``"{qid} Q0 {pid} {rank} {200-rank
 per-query passage-id de-duplication leaves the unused tail slots at ``(0, 0)`` (:243-255), and a
 query id that occurs twice reuses the first occurrence's list (:241-246).
 ``print_trec_res`` restates the metric block (:288-353) with trec_eval's published definitions, because
-``pytrec_eval`` is not installable here: **parity unpinned** for it (no reference output to compare with; the
-unit test is hand-worked).  Pass ``evaluate=`` to plug in pytrec_eval where it exists.
+``pytrec_eval`` is not installable here: **parity unpinned** against it (no reference output to compare with; the unit
+tests are hand-worked and a randomized cross-check against scikit-learn's ndcg_score).  Pass ``evaluate=`` to plug in pytrec_eval where it exists.
 """
 import logging
 import math

@@ -143,6 +143,42 @@ def test_trec_metrics_hand_worked(tmp_path):
     assert res2["Recall@10"] == round((1.0 + 0.0) / 2 * 100, 5)
 
 
+def test_trec_metrics_against_an_independent_implementation(tmp_path):
+    """pytrec_eval cannot be installed here, so print_trec_res stays 'parity unpinned' against it; this pins its NDCG@3
+    against a second, independent implementation instead (scikit-learn's ndcg_score: linear gains, log2 discounts, ideal
+    ranking over every judged document) and MRR / recall against direct recomputation, on random runs and judgements."""
+    from sklearn.metrics import ndcg_score
+    from haconvdr_amd.trec import print_trec_res
+    rng = np.random.default_rng(2024)
+    n_q, n_docs, depth = 40, 60, 25
+    qrel_lines, run_lines, expect = [], [], {"ndcg": [], "mrr": [], "r10": []}
+    for qi in range(n_q):
+        qid = f"q{qi}"
+        judged = rng.choice(n_docs, size=int(rng.integers(3, 15)), replace=False)
+        grades = {int(d): int(rng.integers(0, 4)) for d in judged}
+        if not any(g > 0 for g in grades.values()):
+            grades[int(judged[0])] = 2
+        for d, g in grades.items():
+            qrel_lines.append(f"{qid} 0 d{d} {g}\n")
+        ranked = [int(d) for d in rng.permutation(n_docs)[:depth]]
+        for i, d in enumerate(ranked):
+            run_lines.append(f"{qid} Q0 d{d} {i + 1} {200 - i - 1} {50.0 - i} ance\n")
+        docs = sorted(set(ranked) | set(grades))
+        y_true = np.array([[max(grades.get(d, 0), 0) for d in docs]], float)
+        y_score = np.array([[200 - ranked.index(d) - 1 if d in ranked else -1.0 for d in docs]], float)
+        expect["ndcg"].append(ndcg_score(y_true, y_score, k=3, ignore_ties=True))
+        rel = {d for d, g in grades.items() if g >= 1}
+        first = next((i for i, d in enumerate(ranked) if d in rel), None)
+        expect["mrr"].append(0.0 if first is None else 1.0 / (first + 1))
+        expect["r10"].append(len(rel & set(ranked[:10])) / len(rel))
+    (tmp_path / "qrel.txt").write_text("".join(qrel_lines))
+    (tmp_path / "run.trec").write_text("".join(run_lines))
+    res = print_trec_res(str(tmp_path / "run.trec"), str(tmp_path / "qrel.txt"), rel_threshold=1)
+    assert abs(res["NDCG@3"] - np.mean(expect["ndcg"]) * 100) < 1e-4
+    assert abs(res["MRR"] - np.mean(expect["mrr"]) * 100) < 1e-4
+    assert abs(res["Recall@10"] - np.mean(expect["r10"]) * 100) < 1e-4
+
+
 def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus N` with no launcher: the parent starts N ranks (RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_* set, loopback rendezvous), waits for all of them, and fails when a rank fails."""
