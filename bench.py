@@ -65,7 +65,7 @@ def spawn_ranks(n, argv):
     if "--spawn-selftest" not in argv:
         import torch
         have = torch.cuda.device_count()
-        if have < n:
+        if have < n and not (have >= 1 and os.environ.get("HAC_BENCH_REHEARSAL") == "1"):
             raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -157,11 +157,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} launched with WORLD_SIZE={world}")
+    # HAC_BENCH_REHEARSAL=1 (development only, the JSON line says so): the N ranks share the GPUs that are present and talk
+    # over gloo -- RCCL refuses two ranks on one device -- so that the N > 1 control flow can be exercised on a 1-GPU box.
+    rehearsal = world > 1 and os.environ.get("HAC_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from haconvdr_amd import synth
     from haconvdr_amd.encoder import ANCEEncoder
@@ -324,6 +332,8 @@ def main():
         "roofline": roofline,
         "cpu_baseline": None,
     }
+    if rehearsal:
+        out["rehearsal"] = f"NOT a measurement: {world} ranks share {torch.cuda.device_count()} GPU(s) over gloo (HAC_BENCH_REHEARSAL=1)"
     extras = {}
 
     # ---- CPU baseline (rank 0, N = 1): the oracle on the host cores, bounded sample of the same workload ----

@@ -476,6 +476,38 @@ def test_cfg4_shard_under_an_nccl_group(oracle):
     assert torch.equal(I1, I) and torch.equal(D1, D)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_search_across_ranks_sharing_the_gpu(world, oracle, tmp_path):
+    """SURVEY §8(e) with more than one rank on the real HIP path: `world` processes (tests/_sharded_gpu_rank.py) each hold
+    one contiguous shard on the GPU, all-gather the data-parallel query slices and the packed top-k keys, and merge on the
+    device.  The box has one GPU, so the ranks share it and the collectives run over gloo (RCCL wants one device per rank;
+    the single-rank RCCL case is test_cfg4_shard_under_an_nccl_group).  Expected: the oracle over the whole corpus, with
+    ties (duplicated rows living in different shards) broken by global position."""
+    import socket
+    import subprocess
+    import sys
+    n, nq, k = 30011, 37, 100
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "rank0.npz")
+    script = os.path.join(os.path.dirname(__file__), "_sharded_gpu_rank.py")
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, script, out, str(n), str(nq), str(k)], env=env))
+    try:
+        codes = [p.wait(timeout=300) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert codes == [0] * world
+    got = np.load(out)
+    x, q, _ = cases.search_case_inputs("dup", 0x5AAD, n, nq)
+    assert_same(got["D"], got["I"], *oracle.flat_ip_search(x, q, k))
+
+
 def test_resident_corpus_many_searches(tmp_path, oracle):
     """Blocks loaded once (zero-copy mmap of the pickled payload), searched repeatedly."""
     from haconvdr_amd.passages import write_embedding_block
