@@ -622,29 +622,29 @@ struct AttnArgs {
 //                 m = 16*s2 + 8(j>>2) + 4hh + (j&3), i.e. key pi(m) = 16*s2 + 8hh + j  -- eight consecutive
 //                 keys, which is what a V piece holds.  Output: lane (query r, hh), accumulator e <-> d =
 //                 32t + (e&3) + 8(e>>2) + 4hh: four consecutive features per lane, 1/l is lane-local.
-template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void attention_kernel(AttnArgs a) {
+template <int WAVES, int U>
+__global__ __launch_bounds__(WAVES * 64, WAVES * U == 8 ? 2 : 1) void attention_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.y, head = blockIdx.x;
     const int len32 = a.s.len32[b];
-    if ((len32 > 256) != (WAVES == 8)) return;  // the other instantiation's sequence (whole workgroup leaves)
+    if ((len32 > 256) != (WAVES * U == 16)) return;  // the other instantiation's sequence (whole workgroup leaves)
     const int len = a.s.lens[b];
     const size_t base = (size_t)a.s.off[b];
     const int r = lane & 31, hh = lane >> 5;
     const int nkb = len32 >> 5;
-    const int q0 = w * 64;
+    const int q0 = w * 32 * U;
     const bool active = q0 < len32 && !(a.cls_only && w != 0);
     unsigned char *vimg = smem + len32 * 128;
 
     typedef const __attribute__((address_space(1))) void *gvp;
     typedef __attribute__((address_space(3))) void *lvp;
     // Q^T fragments (B operand of S^T): lane (q = r, half hh) holds q[16*ks + 8*hh .. +8)
-    bf16x8 qf[2][4];
+    bf16x8 qf[U][4];
     if (active) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
             const bf16 *qrow = a.q + (base + q0 + u * 32 + r) * H + head * DH + 8 * hh;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) qf[u][ks] = *reinterpret_cast<const bf16x8 *>(qrow + ks * 16);
@@ -670,13 +670,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void attention_kern
     auto key_of = [&](int e) { return (e & 3) + 4 * ((e >> 2) & 1) + 8 * hh + 16 * (e >> 3); };
 
     // pass 1: row maxima
-    float mxs[2] = {0.f, 0.f};
+    float mxs[U] = {};
     if (active) {
-        float mx[2] = {-INFINITY, -INFINITY};
-        for (int kb = 0; kb < nkb; ++kb) {
-            f32x16 s[2];
+        float mx[U];
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < U; ++u) mx[u] = -INFINITY;
+        for (int kb = 0; kb < nkb; ++kb) {
+            f32x16 s[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) s[u][e] = 0.f;
             const unsigned char *kp = krow + kb * 4096;
@@ -684,34 +686,33 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void attention_kern
             for (int ks = 0; ks < 4; ++ks) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(kp + (((2 * ks + hh) ^ sw) << 4));
 #pragma unroll
-                for (int u = 0; u < 2; ++u) s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[u][ks], s[u], 0, 0, 0);
+                for (int u = 0; u < U; ++u) s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[u][ks], s[u], 0, 0, 0);
             }
             if (kb * 32 + 32 <= len) {   // whole block valid (wave-uniform): no per-key masking
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    mx[0] = fmaxf(mx[0], s[0][e]);
-                    mx[1] = fmaxf(mx[1], s[1][e]);
-                }
+                for (int e = 0; e < 16; ++e)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) mx[u] = fmaxf(mx[u], s[u][e]);
             } else {
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
                     if (kb * 32 + key_of(e) < len) {
-                        mx[0] = fmaxf(mx[0], s[0][e]);
-                        mx[1] = fmaxf(mx[1], s[1][e]);
+#pragma unroll
+                        for (int u = 0; u < U; ++u) mx[u] = fmaxf(mx[u], s[u][e]);
                     }
             }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) mxs[u] = fmaxf(mx[u], __shfl_xor(mx[u], 32));
+        for (int u = 0; u < U; ++u) mxs[u] = fmaxf(mx[u], __shfl_xor(mx[u], 32));
     }
     __syncthreads();  // V is resident (drains this wave's DMA, then meets the others)
     if (!active) return;
 
     // pass 2: P = exp(S - max), l = sum P, O^T = V^T.P^T
-    float lsum[2] = {0.f, 0.f};
-    f32x16 o[2][2];
+    float lsum[U] = {};
+    f32x16 o[U][2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -725,15 +726,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void attention_kern
     for (int ks = 0; ks < 4; ++ks) kc[ks] = *reinterpret_cast<const bf16x8 *>(krow + (((2 * ks + hh) ^ sw) << 4));
     auto step = [&](int kb, auto masked_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
-        f32x16 s[2];
+        f32x16 s[U];
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int e = 0; e < 16; ++e) s[u][e] = -mxs[u];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc[ks], qf[u][ks], s[u], 0, 0, 0);
+            for (int u = 0; u < U; ++u) s[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc[ks], qf[u][ks], s[u], 0, 0, 0);
         const unsigned char *vp = vlane + kb * 4096;
         bf16x8 vf[2][2];
 #pragma unroll
@@ -745,12 +746,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void attention_kern
         for (int ks = 0; ks < 4; ++ks) kc[ks] = *reinterpret_cast<const bf16x8 *>(kp + (((2 * ks + hh) ^ sw) << 4));
         // raw v_exp_f32: arguments are <= 0 (up to rounding), results in (0,1]; libm's exp2f wraps every
         // call in range checks and ldexp, 5 VALU instead of 1
-        bf16x8 pf[2][2];
+        bf16x8 pf[U][2];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const bool valid = !MASKED || kb * 32 + key_of(e) < len;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const float p = valid ? __builtin_amdgcn_exp2f(s[u][e]) : 0.f;
                 lsum[u] += p;
                 pf[u][e >> 3][e & 7] = (bf16)p;
@@ -761,14 +762,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void attention_kern
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int u = 0; u < 2; ++u) o[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s2][t], pf[u][s2], o[u][t], 0, 0, 0);
+                for (int u = 0; u < U; ++u) o[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s2][t], pf[u][s2], o[u][t], 0, 0, 0);
     };
     const int nfull = len >> 5;  // key blocks without padding keys (nkb - nfull is 0 or 1)
     for (int kb = 0; kb < nfull; ++kb) step(kb, std::false_type{});
     if (nfull < nkb) step(nfull, std::true_type{});
 
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < U; ++u) {
         if (q0 + u * 32 >= len32 || (a.cls_only && u)) break;  // past the sequence (computed on foreign rows) or not needed
         const float inv = 1.0f / (lsum[u] + __shfl_xor(lsum[u], 32));
         bf16 *crow = a.ctx + (base + q0 + u * 32 + r) * H + head * DH + 4 * hh;
@@ -784,6 +785,248 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void attention_kern
                 *reinterpret_cast<bf16x4 *>(crow + 32 * t + 8 * g4) = ov;
             }
     }
+}
+
+// ------------------------------------------------------------------ attention, streaming form
+// The two-pass kernel above keeps a head's whole K and V in LDS: one workgroup per CU for 257+ rows, and (in-kernel stamps,
+// L = 512) 10 k of a workgroup's 49 k cycles go to waiting for K with nothing else on the CU -- every CU loading at once, at the
+// chip's HBM rate; an item moves 256 KiB (Q, K, V in, context out), 40 % of the kernel's time at that rate.  Here the
+// workgroups are persistent and K/V arrive as a continuous stream of chunks through a 3-stage LDS ring that runs on across
+// the (sequence, head) items, two chunks ahead of the arithmetic, one K piece and one V piece per wave and chunk; the next
+// item's Q rows are staged through LDS the same way.  K passes through once: the softmax is the online form (running
+// reference m per query row, P = 2^(s - m) with the accumulator started at -m; m is only raised, exactly, when a block's
+// maximum exceeds it by more than 2^8 -- then l and O are rescaled -- so P <= 256 and the common step has no rescale).
+//   WAVES = 16: sequences of 257..512 rows, chunks of 128 keys, 160 KiB of LDS, one workgroup per CU;
+//   WAVES = 8 : up to 256 rows, chunks of 64 keys, 80 KiB, two workgroups per CU.
+// Index algebra, LDS images of a K row block and of a V piece: as in attention_kernel.  vmcnt is in order; every wave
+// issues the same DMA instructions per chunk (pieces past the sequence are redirected to a valid piece of the right
+// parity, the exhausted stream re-reads its last chunk), so the waits can be counted: at a chunk's barrier the two youngest
+// DMAs (the next chunk's) may stay in flight; at an item's first chunk everything but this wave's own context stores is
+// waited for (the item's Q pieces were issued at least one chunk earlier).
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 4) void attention_stream_kernel(AttnArgs a, int n_items) {
+    constexpr int CHUNK = WAVES * 8;             // keys per ring stage
+    constexpr int STEPS = CHUNK / 32;            // 32-key steps per chunk
+    constexpr int NS = 3;                        // ring stages: the stream runs NS - 1 chunks ahead
+    constexpr int STAGE = CHUNK * 256;           // bytes: K rows (CHUNK x 128) | V pieces (CHUNK x 128)
+    constexpr int QBYTES = WAVES * 32 * 128;     // the item's Q rows
+    constexpr float TAU = 8.0f;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *const ring = smem + QBYTES;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int G = gridDim.x;
+    typedef const __attribute__((address_space(1))) void *gvp;
+    typedef __attribute__((address_space(3))) void *lvp;
+    // the sequence table is read with scalar loads, by hand: inside these loops hipcc would use vector loads and wait
+    // vmcnt(0) for each, draining the DMA stream
+    auto sload = [&](const int *p, int i) {
+        int v;
+        asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p), "s"(i * 4) : "memory");
+        return v;
+    };
+    auto next_item = [&](int t) {   // the next (sequence, head) of this workgroup and of this instantiation's length class
+        t += G;
+        while (t < n_items) {
+            const int l32 = sload(a.s.len32, t / NH);
+            if (l32 > 0 && (l32 > 256) == (WAVES == 16)) break;   // (an empty sequence has no rows: nothing to do, nothing to read)
+            t += G;
+        }
+        return t;
+    };
+    struct Item { int len, len32, head, nch; size_t base; };
+    auto describe = [&](int t) {
+        const int b = t / NH;
+        Item it;
+        it.head = t - b * NH;
+        it.len = sload(a.s.lens, b);
+        it.len32 = sload(a.s.len32, b);
+        it.base = (size_t)sload(a.s.off, b);
+        it.nch = (it.len32 + CHUNK - 1) / CHUNK;
+        return it;
+    };
+    // DMA source = workgroup-uniform base (SGPRs) + a 32-bit lane offset, recomputed at each use (kept live across the
+    // arithmetic it would be spilled, and a scratch reload is a vmcnt(0)).  A K or Q piece is 8 rows, 8p + (lane>>3): the
+    // GEMM swizzle term of its rows is ((p&1)*4 + (lane>>4)) & 7, and every piece of this wave has the parity of w.
+    auto k_lane = [&]() {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        return (unsigned)((l >> 3) * H + ((l & 7) ^ ((((w & 1) << 2) + (l >> 4)) & 7)) * 8);
+    };
+    auto v_lane = [&]() {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        return (unsigned)((l & 31) * 16 + (l >> 5) * 8);
+    };
+    auto issue_q = [&](const Item &it) {   // 4 pieces per wave into the Q region (slot = piece)
+        const int p_last = (it.len32 >> 3) - 2 + (w & 1);
+        const bf16 *src = a.q + it.base * H + it.head * DH;
+        const unsigned kl = k_lane();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = w + WAVES * j;
+            __builtin_amdgcn_global_load_lds((gvp)(src + (size_t)min(p, p_last) * 8 * H + kl), (lvp)(smem + p * 1024), 16, 0, 0);
+        }
+    };
+    // ---- the K/V stream (runs NS - 1 chunks ahead of the arithmetic, across items)
+    int s_t, s_c = 0, s_stage = 0;
+    Item s_it;
+    bool s_more = true;
+    auto stream_issue = [&]() {
+        const int p = min(s_c * WAVES + w, (s_it.len32 >> 3) - 2 + (w & 1));          // K piece (8 rows)
+        const int gi = min(s_c * (CHUNK / 16) + (w >> 1), (s_it.len32 >> 4) - 1);      // V piece: 16-key group gi, d-tile w & 1
+        unsigned char *dst = ring + s_stage * STAGE + w * 1024;
+        __builtin_amdgcn_global_load_lds((gvp)(a.k + s_it.base * H + s_it.head * DH + (size_t)p * 8 * H + k_lane()), (lvp)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gvp)(a.v16 + (((s_it.base >> 4) + gi) * H + s_it.head * DH + (w & 1) * 32) * 16 + v_lane()),
+                                         (lvp)(dst + CHUNK * 128), 16, 0, 0);
+        s_stage = s_stage + 1 == NS ? 0 : s_stage + 1;
+        if (s_more && ++s_c == s_it.nch) {
+            const int t2 = next_item(s_t);
+            if (t2 < n_items) {
+                s_t = t2;
+                s_it = describe(t2);
+                s_c = 0;
+            } else {
+                s_more = false;   // exhausted: the remaining issues re-read this chunk into the free stage (the counts stay exact)
+                s_c = s_it.nch - 1;
+            }
+        }
+    };
+    const int pr = (r & 19) | ((r & 4) << 1) | ((r & 8) >> 1);  // pi(r)
+    const int sw = (pr >> 1) & 7;
+    auto key_of = [&](int e) { return (e & 3) + 4 * ((e >> 2) & 1) + 8 * hh + 16 * (e >> 3); };
+
+    int t = next_item((int)blockIdx.x - G);
+    if (t >= n_items) return;
+    Item cur = describe(t);
+    s_t = t;
+    s_it = cur;
+    issue_q(cur);
+#pragma unroll
+    for (int i = 0; i < NS - 1; ++i) stream_issue();
+    bool stored = false;   // this wave's 8 context stores are the youngest entries of its queue
+    int c_stage = 0;
+    bf16x8 qf[4];
+    for (;;) {
+        const int tn = next_item(t);
+        const bool has_next = tn < n_items;
+        const Item nxt = describe(has_next ? tn : t);
+        const int len = cur.len, nkb = cur.len32 >> 5;
+        const int nfull = len >> 5;            // key blocks without padding keys (nkb - nfull is 0 or 1)
+        const bool active = w * 32 < cur.len32 && !(a.cls_only && w != 0);
+        float m_ref = 0.f, lsum = 0.f;
+        f32x16 o[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[tt][e] = 0.f;
+        auto step = [&](const unsigned char *stage, int kk, int kb, auto masked_tag) {
+            constexpr bool MASKED = decltype(masked_tag)::value;
+            f32x16 s;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[e] = -m_ref;          // 0 at the item's first block
+            const unsigned char *kp = stage + kk * 4096 + pr * 128;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(kp + (((2 * ks + hh) ^ sw) << 4));
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+            }
+            // this lane's 16 keys of the block, relative to the reference
+            float mloc = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (!MASKED || kb * 32 + key_of(e) < len) mloc = fmaxf(mloc, s[e]);
+            const bool first = kb == 0;
+            if (first || __builtin_amdgcn_ballot_w64(mloc > TAU) != 0) {   // (wave-uniform) move the reference, exactly
+                const float mrow = fmaxf(mloc, __shfl_xor(mloc, 32));       // the query row's maximum over the block
+                const float delta = first ? mrow : (mrow > TAU ? mrow : 0.f);
+                const float sc = first ? 1.f : __builtin_amdgcn_exp2f(-delta);   // (first block: l and O are still zero)
+                m_ref += delta;
+                lsum *= sc;
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[tt][e] *= sc;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s[e] -= delta;
+            }
+            bf16x8 pf[2];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const bool valid = !MASKED || kb * 32 + key_of(e) < len;
+                const float p = valid ? __builtin_amdgcn_exp2f(s[e]) : 0.f;
+                lsum += p;
+                pf[e >> 3][e & 7] = (bf16)p;
+            }
+            // V fragments only now: four waves per SIMD hide the LDS round trip, and the registers of s are free again
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned char *vp = stage + CHUNK * 128 + kk * 4096 + lane * 16;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const bf16x8 vf = *reinterpret_cast<const bf16x8 *>(vp + (s2 * 2 + tt) * 1024);
+                    o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], o[tt], 0, 0, 0);
+                }
+        };
+#pragma nounroll
+        for (int c = 0; c < cur.nch; ++c) {
+            if (c == 0) {
+                if (stored) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (NS - 2)) : "memory");
+            }
+            __builtin_amdgcn_s_barrier();      // this chunk has landed (every wave's pieces); the stage two back is free
+            __builtin_amdgcn_sched_barrier(0);
+            stream_issue();
+            if (c == 0) {
+                if (active) {                  // Q^T fragments (B operand of S^T): lane (q = r, half hh) holds q[16*ks + 8*hh .. +8)
+                    const unsigned char *qrow = smem + (w * 32 + r) * 128;
+                    const int qsw = (r >> 1) & 7;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8 *>(qrow + (((2 * ks + hh) ^ qsw) << 4));
+                }
+                if (cur.nch == 1) {            // no later barrier of this item: make one, the Q region is rewritten below
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (has_next) issue_q(nxt);
+                }
+            } else if (c == 1) {
+                if (has_next) issue_q(nxt);    // every wave has read its Q fragments (it passed this chunk's barrier)
+            }
+            if (active) {
+                const unsigned char *stage = ring + c_stage * STAGE;
+                const int kb_hi = min(nfull, (c + 1) * STEPS);   // blocks without padding keys: the common step
+#pragma nounroll
+                for (int kb = c * STEPS; kb < kb_hi; ++kb) step(stage, kb - c * STEPS, kb, std::false_type{});
+                if (c == cur.nch - 1 && nfull < nkb) step(stage, nfull - c * STEPS, nfull, std::true_type{});
+            }
+            c_stage = c_stage + 1 == NS ? 0 : c_stage + 1;
+        }
+        if (active) {                          // 8 stores of 8 bytes, by instruction: the wait at the next item's first chunk counts them
+            const float inv = 1.0f / (lsum + __shfl_xor(lsum, 32));
+            bf16 *crow = a.ctx + (cur.base + w * 32 + r) * H + cur.head * DH + 4 * hh;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    bf16x4 ov;
+                    ov.x = (bf16)(o[tt][g4 * 4 + 0] * inv);
+                    ov.y = (bf16)(o[tt][g4 * 4 + 1] * inv);
+                    ov.z = (bf16)(o[tt][g4 * 4 + 2] * inv);
+                    ov.w = (bf16)(o[tt][g4 * 4 + 3] * inv);
+                    asm volatile("global_store_dwordx2 %0, %1, off offset:%2" ::"v"(crow), "v"(ov), "n"((32 * tt + 8 * g4) * 2) : "memory");
+                }
+        }
+        stored = active;
+        if (!has_next) break;
+        cur = nxt;
+        t = tn;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stream's last read-ahead writes LDS: it must land before the workgroup ends
 }
 
 // Last layer: everything after attention is only needed for the <s> row of each sequence
@@ -899,6 +1142,7 @@ struct hac_encoder {
     GrowBuf ws_x, ws_xb, ws_q, ws_k, ws_vt, ws_ctx, ws_y, ws_h, ws_seq, ws_ids, ws_mask, ws_out, ws_cls, ws_stats;
     GrowBuf ws_yb, ws_part, ws_idstats;   // gemm8 path: bf16 copy of the attention-block rows, row-sum partials, (0, 1) statistics
     size_t idstats_rows = 0;
+    int attn_mode = 0;                    // 0: streaming single-pass attention; 1: two-pass kernels (cross-check)
     int gemm_mode = -1;                   // -1: by size, 0: classic kernels only, 1: gemm8 whenever the batch has a full tile (tests)
     void *h_pin = nullptr;
     size_t h_pin_bytes = 0;
@@ -1065,8 +1309,13 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
         AttnArgs a{q, k, vt, ctx, s, last ? 1 : 0};
         // sequences of <= 256 rows: 4-wave workgroups; longer ones: 8-wave workgroups (each skips the other's)
         HAC_TRY(prof_begin(e, 1 + HAC_ENC_CLASS_ATTN, st));
-        attention_kernel<4><<<dim3(NH, B), dim3(256), (size_t)(L32 < 256 ? L32 : 256) * 256, st>>>(a);
-        if (L32 > 256) attention_kernel<8><<<dim3(NH, B), dim3(512), (size_t)L32 * 256, st>>>(a);
+        if (e->attn_mode == 0) {           // persistent streaming kernels, one launch per length class
+            attention_stream_kernel<8><<<dim3(2 * e->n_cu), dim3(512), 81920, st>>>(a, NH * B);
+            if (L32 > 256) attention_stream_kernel<16><<<dim3(e->n_cu), dim3(1024), 163840, st>>>(a, NH * B);
+        } else {                           // two-pass kernels, one workgroup per (sequence, head): kept as a cross-check
+            attention_kernel<8, 1><<<dim3(NH, B), dim3(512), (size_t)(L32 < 256 ? L32 : 256) * 256, st>>>(a);
+            if (L32 > 256) attention_kernel<16, 1><<<dim3(NH, B), dim3(1024), (size_t)L32 * 256, st>>>(a);
+        }
         HAC_TRY(prof_end(e, 1 + HAC_ENC_CLASS_ATTN, st));
         // Residual stream between layers: layer 0 reads the embedding rows x (normalized); afterwards the
         // stream lives as pre-LayerNorm rows + (mean, rstd): yF/statsF after a layer's FFN, yA/statsA after its
@@ -1202,8 +1451,10 @@ int hac_encoder_create(const hac_encoder_config *cfg, int device, hac_encoder **
         delete e;
         return fail(HAC_ERR_HIP, "hipStreamCreate failed");
     }
-    (void)hipFuncSetAttribute((const void *)attention_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    (void)hipFuncSetAttribute((const void *)attention_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void *)attention_kernel<8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void *)attention_kernel<16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void *)attention_stream_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
+    (void)hipFuncSetAttribute((const void *)attention_stream_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
     (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_QKV, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
     (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_RESID, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
     (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_GELU, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
@@ -1392,6 +1643,7 @@ int hac_encoder_set_option(hac_encoder *e, const char *name, const char *value) 
     if (!e || !name || !value) return fail(HAC_ERR_INVALID, "set_option: null argument");
     const std::string n(name), v(value);
     if (n == "gemm") e->gemm_mode = v == "classic" ? 0 : (v == "8phase" ? 1 : -1);
+    else if (n == "attn") e->attn_mode = v == "twopass" ? 1 : 0;
     else if (n == "max_tokens") e->max_tokens = std::max<long>(4096, atol(value));
     else return fail(HAC_ERR_INVALID, "unknown encoder option '%s'", name);
     return HAC_OK;
