@@ -61,6 +61,8 @@ struct SeqInfo {
     int *pos;     // [B][L] position ids (HF rule), valid for t < len
     int *err;     // [B] per sequence: 1 mask is not a prefix mask, 2 mask is empty, 4 a token id outside [0, vocab)
     int *nb;      // [1] number of sequences (device copy; row count of the CLS-only tail)
+    int *order;   // [B] the attention kernels' work list: sequences of 257+ rows, longest first, then the others, longest first
+    int *ncls;    // [2] how many of each (empty sequences are in neither)
 };
 
 // one workgroup per sequence: len = sum(mask), prefix check, HF position ids
@@ -122,6 +124,34 @@ __global__ void seq_offsets_kernel(SeqInfo s, int B) {
         }
         s.off[B] = acc;
         *s.nb = B;
+    }
+}
+
+// The streaming attention kernels are persistent: workgroup g takes items g, g + G, ... of its length class.  With the
+// sequences ordered by length inside a class every workgroup gets one item of each length stratum (and the short ones
+// last), so the static deal is balanced; a counting sort over the 16 possible padded lengths, one workgroup.
+__global__ __launch_bounds__(256) void attn_order_kernel(SeqInfo s, int B) {
+    __shared__ int hist[17], start[17];
+    const int tid = threadIdx.x;
+    if (tid < 17) hist[tid] = 0;
+    __syncthreads();
+    for (int b = tid; b < B; b += 256) atomicAdd(&hist[min(s.len32[b] >> 5, 16)], 1);
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int k = 16; k >= 1; --k) {
+            if (k == 8) s.ncls[0] = acc;      // 9..16 blocks of 32 rows: the long class
+            start[k] = acc;
+            acc += hist[k];
+        }
+        s.ncls[1] = acc - s.ncls[0];
+    }
+    __syncthreads();
+    if (tid < 17) hist[tid] = 0;
+    __syncthreads();
+    for (int b = tid; b < B; b += 256) {
+        const int k = min(s.len32[b] >> 5, 16);
+        if (k > 0) s.order[start[k] + atomicAdd(&hist[k], 1)] = b;
     }
 }
 
@@ -804,7 +834,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES * U == 8 ? 2 : 1) void attention_
 // DMAs (the next chunk's) may stay in flight; at an item's first chunk everything but this wave's own context stores is
 // waited for (the item's Q pieces were issued at least one chunk earlier).
 template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64, 4) void attention_stream_kernel(AttnArgs a, int n_items) {
+__global__ __launch_bounds__(WAVES * 64, 4) void attention_stream_kernel(AttnArgs a) {
     constexpr int CHUNK = WAVES * 8;             // keys per ring stage
     constexpr int STEPS = CHUNK / 32;            // 32-key steps per chunk
     constexpr int NS = 3;                        // ring stages: the stream runs NS - 1 chunks ahead
@@ -826,20 +856,17 @@ __global__ __launch_bounds__(WAVES * 64, 4) void attention_stream_kernel(AttnArg
         asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p), "s"(i * 4) : "memory");
         return v;
     };
-    auto next_item = [&](int t) {   // the next (sequence, head) of this workgroup and of this instantiation's length class
-        t += G;
-        while (t < n_items) {
-            const int l32 = sload(a.s.len32, t / NH);
-            if (l32 > 0 && (l32 > 256) == (WAVES == 16)) break;   // (an empty sequence has no rows: nothing to do, nothing to read)
-            t += G;
-        }
-        return t;
-    };
+    // items of this instantiation's length class: (position in the class's part of the work list, head)
+    const int n_long = sload(a.s.ncls, 0);
+    const int list0 = WAVES == 16 ? 0 : n_long;
+    const int n_items = (WAVES == 16 ? n_long : sload(a.s.ncls, 1)) * NH;
+    auto next_item = [&](int t) { return t + G; };
     struct Item { int len, len32, head, nch; size_t base; };
     auto describe = [&](int t) {
-        const int b = t / NH;
+        const int pos = t / NH;
+        const int b = sload(a.s.order, list0 + pos);
         Item it;
-        it.head = t - b * NH;
+        it.head = t - pos * NH;
         it.len = sload(a.s.lens, b);
         it.len32 = sload(a.s.len32, b);
         it.base = (size_t)sload(a.s.off, b);
@@ -1200,7 +1227,7 @@ int prof_end(hac_encoder *e, int pool, hipStream_t st) {
 
 // carve the sequence bookkeeping of a (sub-)batch out of ws_seq
 int seq_layout(hac_encoder *e, int B, int L, SeqInfo &s) {
-    const size_t seq_ints = (size_t)4 * B + 4 + (size_t)B * L;
+    const size_t seq_ints = (size_t)5 * B + 6 + (size_t)B * L;
     HAC_TRY(e->ws_seq.reserve(seq_ints * 4));
     int *p = (int *)e->ws_seq.p;
     s.lens = p;
@@ -1208,7 +1235,9 @@ int seq_layout(hac_encoder *e, int B, int L, SeqInfo &s) {
     s.off = p + 2 * B;          // B+1 entries
     s.nb = p + 3 * B + 2;
     s.err = p + 3 * B + 4;      // B entries
-    s.pos = p + 4 * B + 4;
+    s.order = p + 4 * B + 4;    // B entries
+    s.ncls = p + 5 * B + 4;     // 2 entries
+    s.pos = p + 5 * B + 6;
     return HAC_OK;
 }
 
@@ -1233,6 +1262,7 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
     HAC_TRY(seq_layout(e, B, L, s));
     seq_prep_kernel<IT><<<dim3(B), dim3(512), 0, st>>>(ids, mask, L, s, c.pad_token_id, c.vocab);
     seq_offsets_kernel<<<dim3(1), dim3(64), 0, st>>>(s, B);
+    attn_order_kernel<<<dim3(1), dim3(256), 0, st>>>(s, B);
     float *x = (float *)e->ws_x.p, *y = (float *)e->ws_y.p;
     float2 *statsA = (float2 *)e->ws_stats.p, *statsF = statsA + Mp;
     bf16 *xb = (bf16 *)e->ws_xb.p, *q = (bf16 *)e->ws_q.p, *k = (bf16 *)e->ws_k.p, *vt = (bf16 *)e->ws_vt.p;
@@ -1310,8 +1340,8 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
         // sequences of <= 256 rows: 4-wave workgroups; longer ones: 8-wave workgroups (each skips the other's)
         HAC_TRY(prof_begin(e, 1 + HAC_ENC_CLASS_ATTN, st));
         if (e->attn_mode == 0) {           // persistent streaming kernels, one launch per length class
-            attention_stream_kernel<8><<<dim3(2 * e->n_cu), dim3(512), 81920, st>>>(a, NH * B);
-            if (L32 > 256) attention_stream_kernel<16><<<dim3(e->n_cu), dim3(1024), 163840, st>>>(a, NH * B);
+            if (L32 > 256) attention_stream_kernel<16><<<dim3(e->n_cu), dim3(1024), 163840, st>>>(a);
+            attention_stream_kernel<8><<<dim3(2 * e->n_cu), dim3(512), 81920, st>>>(a);
         } else {                           // two-pass kernels, one workgroup per (sequence, head): kept as a cross-check
             attention_kernel<8, 1><<<dim3(NH, B), dim3(512), (size_t)(L32 < 256 ? L32 : 256) * 256, st>>>(a);
             if (L32 > 256) attention_kernel<16, 1><<<dim3(NH, B), dim3(1024), (size_t)L32 * 256, st>>>(a);
