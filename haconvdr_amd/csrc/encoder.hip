@@ -833,6 +833,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES * U == 8 ? 2 : 1) void attention_
 // parity, the exhausted stream re-reads its last chunk), so the waits can be counted: at a chunk's barrier the two youngest
 // DMAs (the next chunk's) may stay in flight; at an item's first chunk everything but this wave's own context stores is
 // waited for (the item's Q pieces were issued at least one chunk earlier).
+#ifdef ATT_STAMP   // development: s_memtime stamps of one workgroup's 4th item (tools/probes/attn_stream_probe.hip reads them)
+__device__ unsigned long long g_att_stamps[16 * 32];
+#define ATTS_T(i) do { if (blockIdx.x == 5 && n_done == 3 && lane == 0) g_att_stamps[w * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ATTS_T(i) do { } while (0)
+#endif
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64, 4) void attention_stream_kernel(AttnArgs a) {
     constexpr int CHUNK = WAVES * 8;             // keys per ring stage
@@ -935,7 +941,8 @@ __global__ __launch_bounds__(WAVES * 64, 4) void attention_stream_kernel(AttnArg
     bool stored = false;   // this wave's 8 context stores are the youngest entries of its queue
     int c_stage = 0;
     bf16x8 qf[4];
-    for (;;) {
+    for (int n_done = 0;; ++n_done) {
+        ATTS_T(0);
         const int tn = next_item(t);
         const bool has_next = tn < n_items;
         const Item nxt = describe(has_next ? tn : t);
@@ -999,6 +1006,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void attention_stream_kernel(AttnArg
         };
 #pragma nounroll
         for (int c = 0; c < cur.nch; ++c) {
+            ATTS_T(1 + 4 * c);
             if (c == 0) {
                 if (stored) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1007,6 +1015,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void attention_stream_kernel(AttnArg
             }
             __builtin_amdgcn_s_barrier();      // this chunk has landed (every wave's pieces); the stage two back is free
             __builtin_amdgcn_sched_barrier(0);
+            ATTS_T(2 + 4 * c);
             stream_issue();
             if (c == 0) {
                 if (active) {                  // Q^T fragments (B operand of S^T): lane (q = r, half hh) holds q[16*ks + 8*hh .. +8)
@@ -1024,6 +1033,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void attention_stream_kernel(AttnArg
             } else if (c == 1) {
                 if (has_next) issue_q(nxt);    // every wave has read its Q fragments (it passed this chunk's barrier)
             }
+            ATTS_T(3 + 4 * c);
             if (active) {
                 const unsigned char *stage = ring + c_stage * STAGE;
                 const int kb_hi = min(nfull, (c + 1) * STEPS);   // blocks without padding keys: the common step
@@ -1032,6 +1042,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void attention_stream_kernel(AttnArg
                 if (c == cur.nch - 1 && nfull < nkb) step(stage, nfull - c * STEPS, nfull, std::true_type{});
             }
             c_stage = c_stage + 1 == NS ? 0 : c_stage + 1;
+            ATTS_T(4 + 4 * c);
         }
         if (active) {                          // 8 stores of 8 bytes, by instruction: the wait at the next item's first chunk counts them
             const float inv = 1.0f / (lsum + __shfl_xor(lsum, 32));
@@ -1048,6 +1059,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void attention_stream_kernel(AttnArg
                     asm volatile("global_store_dwordx2 %0, %1, off offset:%2" ::"v"(crow), "v"(ov), "n"((32 * tt + 8 * g4) * 2) : "memory");
                 }
         }
+        ATTS_T(20);
         stored = active;
         if (!has_next) break;
         cur = nxt;

@@ -124,6 +124,35 @@ def test_encoder_vs_oracle_one_layer():
     assert np.abs(out - ref).max() < 0.1
 
 
+@pytest.mark.parametrize("scale", [4.0, 10.0])
+def test_peaked_attention_both_kernels_vs_oracle(scale):
+    """Query and key projections scaled up: attention logits with a standard deviation of ~5 (scale 4) or ~30 (scale 10) instead
+    of the 0.3 of N(0, 0.02^2) weights, i.e. softmax rows dominated by a few keys, block maxima that keep moving.  This is where
+    the streaming kernel's running reference is raised and l, O rescaled (with flat logits that path never runs beyond the
+    first block); the two-pass kernels compute exact row maxima.  Both against the fp32 oracle."""
+    from haconvdr_amd import synth
+    from haconvdr_amd.encoder import ANCEEncoder
+    from oracle import ance_oracle
+    from tests.golden.make_golden_encoder import encoder_case_inputs
+    sd = dict(synth.ance_state_dict(0xFACE, 2))
+    for i in range(2):
+        for nm in ("query", "key"):
+            for part in ("weight", "bias"):
+                key = f"roberta.encoder.layer.{i}.attention.self.{nm}.{part}"
+                sd[key] = (sd[key] * scale).astype(np.float32)
+    enc = ANCEEncoder.from_state_dict(sd)
+    ids, mask = encoder_case_inputs(7, [1, 5, 31, 32, 33, 64, 100, 129, 255, 256, 257, 290, 384, 400, 511, 512], 512)
+    ref = ance_oracle.ance_forward(sd, ids, mask)
+    outs = {}
+    for mode in ("stream", "twopass"):
+        enc.set_option("attn", mode)
+        outs[mode] = enc(ids.astype(np.int32), mask.astype(np.int32))
+        assert np.isfinite(outs[mode]).all()
+        d = one_minus_cos(outs[mode], ref)
+        assert np.all(d < COS_EXPECT), (mode, d)
+    assert one_minus_cos(outs["stream"], outs["twopass"]).max() < COS_EXPECT
+
+
 def test_torch_tensor_path_int64_and_pad_invariance():
     """The reference hands int64 CUDA tensors; results must not depend on what sits in masked
     positions (bit-identical in the reference) nor on the id dtype."""
