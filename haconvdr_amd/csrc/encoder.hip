@@ -961,11 +961,13 @@ __global__ __launch_bounds__(WAVES * 64, 4) void attention_stream_kernel(AttnArg
 #pragma unroll
             for (int e = 0; e < 16; ++e) s[e] = -m_ref;          // 0 at the item's first block
             const unsigned char *kp = stage + kk * 4096 + pr * 128;
+            bf16x8 kf[4];   // all four reads in flight before the first MFMA (left alone hipcc funnels them through one register quad)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(kp + (((2 * ks + hh) ^ sw) << 4));
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
-            }
+            for (int ks = 0; ks < 4; ++ks) kf[ks] = *reinterpret_cast<const bf16x8 *>(kp + (((2 * ks + hh) ^ sw) << 4));
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s, 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // 4 DS reads
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // 4 MFMAs
             // this lane's 16 keys of the block, relative to the reference
             float mloc = -INFINITY;
 #pragma unroll
@@ -996,13 +998,17 @@ __global__ __launch_bounds__(WAVES * 64, 4) void attention_stream_kernel(AttnArg
             // V fragments only now: four waves per SIMD hide the LDS round trip, and the registers of s are free again
             __builtin_amdgcn_sched_barrier(0);
             const unsigned char *vp = stage + CHUNK * 128 + kk * 4096 + lane * 16;
+            bf16x8 vf[2][2];
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    const bf16x8 vf = *reinterpret_cast<const bf16x8 *>(vp + (s2 * 2 + tt) * 1024);
-                    o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[s2], o[tt], 0, 0, 0);
-                }
+                for (int tt = 0; tt < 2; ++tt) vf[s2][tt] = *reinterpret_cast<const bf16x8 *>(vp + (s2 * 2 + tt) * 1024);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s2][tt], pf[s2], o[tt], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         };
 #pragma nounroll
         for (int c = 0; c < cur.nch; ++c) {
