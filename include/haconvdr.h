@@ -173,8 +173,10 @@ int hac_encoder_forward_device(hac_encoder *enc, const void *ids_dev, const void
                                int B, int L, float *out_dev, void *hip_stream);
 /* Tuning and test switches of a live handle: "gemm" = "auto" (by batch size) | "classic" (128^2 / 256^2 two-stage
  * kernels with separate LayerNorm passes) | "8phase" (the large-batch ping-pong kernel with folded LayerNorms whenever
- * the batch has a whole 256-row tile); "max_tokens" = packed rows per sub-batch.  HAC_ENC_GEMM gives the default of
- * "gemm" and is read once, in hac_encoder_create. */
+ * the batch has a whole 256-row tile); "attn" = "stream" (persistent single-pass attention kernels, the default) |
+ * "twopass" (one workgroup per (sequence, head), exact row maxima first: the cross-check of the tests);
+ * "max_tokens" = packed rows per sub-batch.  HAC_ENC_GEMM gives the default of "gemm" and is read once, in
+ * hac_encoder_create. */
 int hac_encoder_set_option(hac_encoder *enc, const char *name, const char *value);
 
 /* Profiling aid for bench.py: hipEvent pairs recorded on the launch stream (no host sync).  mask bit 0:
@@ -183,7 +185,7 @@ int hac_encoder_set_option(hac_encoder *enc, const char *name, const char *value
  * launch order) and clear the record. */
 enum {
     HAC_ENC_CLASS_QKV = 0,       /* gemm_bf16_nt_kernel<EPI_QKV>:   [T,768] x [2304,768]^T + bias, Q scale, V regrouping */
-    HAC_ENC_CLASS_ATTN = 1,      /* attention_kernel<4|8> (both launches of a layer) */
+    HAC_ENC_CLASS_ATTN = 1,      /* attention_stream_kernel<16|8> (both launches of a layer) */
     HAC_ENC_CLASS_OUTPROJ = 2,   /* gemm_bf16_nt_kernel<EPI_RESID>: [T,768] x [768,768]^T + bias + residual (+ LayerNorm statistics) */
     HAC_ENC_CLASS_FFN_UP = 3,    /* gemm_bf16_nt_kernel<EPI_GELU>:  [T,768] x [3072,768]^T + bias + erf GELU */
     HAC_ENC_CLASS_FFN_DOWN = 4,  /* gemm_bf16_nt_kernel<EPI_RESID>: [T,3072] x [768,3072]^T + bias + residual (+ LayerNorm statistics) */

@@ -73,7 +73,7 @@ def main():
     if t:
         out["search_hbm_bytes_per_launch"] = t["total"]
         out["search"] = t
-    for name, needle in (("qkv", "gemm8_kernel<0>"), ("resid", "gemm8_kernel<2>"), ("attention", "attention_kernel<8>"),
+    for name, needle in (("qkv", "gemm8_kernel<0>"), ("resid", "gemm8_kernel<2>"), ("attention", "attention_stream_kernel<16>"),
                          ("rescore", "rescore_kernel")):
         t = traffic(needle)
         if t:
