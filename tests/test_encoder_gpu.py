@@ -153,6 +153,37 @@ def test_peaked_attention_both_kernels_vs_oracle(scale):
     assert one_minus_cos(outs["stream"], outs["twopass"]).max() < COS_EXPECT
 
 
+@pytest.mark.parametrize("lo,hi,n_seq", [(1, 96, 700), (200, 300, 400), (257, 512, 300)])
+def test_streaming_attention_many_items_per_workgroup(lo, hi, n_seq):
+    """The persistent attention kernels walk several (sequence, head) items per workgroup: one- and two-chunk items back to
+    back (lengths 1..96: the Q region is refilled behind an extra barrier), lengths on either side of the 256-row class border,
+    and long sequences of every chunk count.  Same embeddings as the one-workgroup-per-item two-pass kernels (to bf16 noise),
+    no sequence depends on its neighbours, and a handful of rows against the fp32 oracle."""
+    from haconvdr_amd import synth
+    from oracle import ance_oracle
+    from tests.golden.make_golden_encoder import encoder_case_inputs
+    lens = (lo + (synth.uniform_u32(lo * 7 + hi, n_seq) % np.uint32(hi - lo + 1))).astype(np.int64).tolist()
+    L = -(-hi // 32) * 32
+    ids, mask = encoder_case_inputs(lo + hi, lens, L)
+    enc = encoder(2)
+    outs = {}
+    pick = [0, 1, n_seq // 2, n_seq - 1, int(np.argmin(lens)), int(np.argmax(lens))]
+    enc.set_option("gemm", "classic")      # one GEMM family for the big and the six-sequence batch: bit-equal rows
+    try:
+        for mode in ("twopass", "stream"):
+            enc.set_option("attn", mode)
+            outs[mode] = enc(ids.astype(np.int32), mask.astype(np.int32))
+        alone = enc(ids[pick].astype(np.int32), mask[pick].astype(np.int32))
+    finally:
+        enc.set_option("gemm", "auto")
+        enc.set_option("attn", "stream")
+    assert np.isfinite(outs["stream"]).all()
+    assert one_minus_cos(outs["stream"], outs["twopass"]).max() < COS_EXPECT
+    np.testing.assert_array_equal(alone, outs["stream"][pick])
+    ref = ance_oracle.ance_forward(state_dict(2), ids[pick[:3]], mask[pick[:3]])
+    assert one_minus_cos(outs["stream"][pick[:3]], ref).max() < COS_EXPECT
+
+
 def test_torch_tensor_path_int64_and_pad_invariance():
     """The reference hands int64 CUDA tensors; results must not depend on what sits in masked
     positions (bit-identical in the reference) nor on the id dtype."""
