@@ -938,7 +938,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void attention_stream_kernel(AttnArg
     issue_q(cur);
 #pragma unroll
     for (int i = 0; i < NS - 1; ++i) stream_issue();
-    bool stored = false;   // this wave's 8 context stores are the youngest entries of its queue
+    bool stored = false;   // this wave's 4 context stores are the youngest entries of its queue
     int c_stage = 0;
     bf16x8 qf[4];
     for (int n_done = 0;; ++n_done) {
@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void attention_stream_kernel(AttnArg
         for (int c = 0; c < cur.nch; ++c) {
             ATTS_T(1 + 4 * c);
             if (c == 0) {
-                if (stored) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                if (stored) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (NS - 2)) : "memory");
@@ -1050,19 +1050,33 @@ __global__ __launch_bounds__(WAVES * 64, 4) void attention_stream_kernel(AttnArg
             c_stage = c_stage + 1 == NS ? 0 : c_stage + 1;
             ATTS_T(4 + 4 * c);
         }
-        if (active) {                          // 8 stores of 8 bytes, by instruction: the wait at the next item's first chunk counts them
+        if (active) {
+            // Context row: lane (r, hh) holds features 32t + 8g + 4hh + (0..3), i.e. half of each 16-byte group g.  One
+            // v_permlane32_swap per packed register gives lane (r, 0) the whole of the even groups and lane (r, 1) the odd
+            // ones: 4 stores of 16 bytes (each a 32-byte run per row) instead of 8 of 8.  Issued by instruction: the wait at the
+            // next item's first chunk counts them.
             const float inv = 1.0f / (lsum + __shfl_xor(lsum, 32));
-            bf16 *crow = a.ctx + (cur.base + w * 32 + r) * H + cur.head * DH + 4 * hh;
+            bf16 *crow = a.ctx + (cur.base + w * 32 + r) * H + cur.head * DH + 8 * hh;
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    bf16x4 ov;
-                    ov.x = (bf16)(o[tt][g4 * 4 + 0] * inv);
-                    ov.y = (bf16)(o[tt][g4 * 4 + 1] * inv);
-                    ov.z = (bf16)(o[tt][g4 * 4 + 2] * inv);
-                    ov.w = (bf16)(o[tt][g4 * 4 + 3] * inv);
-                    asm volatile("global_store_dwordx2 %0, %1, off offset:%2" ::"v"(crow), "v"(ov), "n"((32 * tt + 8 * g4) * 2) : "memory");
+                for (int j = 0; j < 2; ++j) {
+                    unsigned pe[2], po[2];   // groups 2j (even) and 2j + 1 (odd), this lane's four features of each, packed
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        pe[h2] = pack_bf16(o[tt][(2 * j) * 4 + 2 * h2] * inv, o[tt][(2 * j) * 4 + 2 * h2 + 1] * inv);
+                        po[h2] = pack_bf16(o[tt][(2 * j + 1) * 4 + 2 * h2] * inv, o[tt][(2 * j + 1) * 4 + 2 * h2 + 1] * inv);
+                        // lanes 32..63 of pe <-> lanes 0..31 of po: the lower half-wave now has [own even | partner's even] in
+                        // (pe, po), the upper one [partner's odd | own odd]
+                        const auto sw2 = __builtin_amdgcn_permlane32_swap(pe[h2], po[h2], false, false);
+                        pe[h2] = sw2[0];
+                        po[h2] = sw2[1];
+                    }
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 ov = {pe[0], pe[1], po[0], po[1]};
+                    // s_nop: a store of more than 64 bits may not be followed at once by a VALU write of its data registers
+                    // (hipcc's hazard recognizer inserts the wait states for its own stores; it cannot see into this one)
+                    asm volatile("global_store_dwordx4 %0, %1, off offset:%2\n\ts_nop 1" ::"v"(crow), "v"(ov), "n"((32 * tt + 16 * j) * 2) : "memory");
                 }
         }
         ATTS_T(20);
