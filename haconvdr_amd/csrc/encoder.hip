@@ -950,22 +950,24 @@ __global__ __launch_bounds__(WAVES * 64, 4) void attention_stream_kernel(AttnArg
         const int nfull = len >> 5;            // key blocks without padding keys (nkb - nfull is 0 or 1)
         const bool active = w * 32 < cur.len32 && !(a.cls_only && w != 0);
         float m_ref = 0.f, lsum = 0.f;
-        f32x16 o[2];
+        f32x16 o[2], negm;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) negm[e] = 0.f;
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) o[tt][e] = 0.f;
         auto step = [&](const unsigned char *stage, int kk, int kb, auto masked_tag) {
             constexpr bool MASKED = decltype(masked_tag)::value;
-            f32x16 s;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) s[e] = -m_ref;          // 0 at the item's first block
             const unsigned char *kp = stage + kk * 4096 + pr * 128;
             bf16x8 kf[4];   // all four reads in flight before the first MFMA (left alone hipcc funnels them through one register quad)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) kf[ks] = *reinterpret_cast<const bf16x8 *>(kp + (((2 * ks + hh) ^ sw) << 4));
+            // the accumulator starts at -m: negm is a register tuple kept across the steps (C operand of the first MFMA), rewritten
+            // only when the reference moves -- not 16 v_mov per step
+            f32x16 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], negm, 0, 0, 0);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s, 0, 0, 0);
+            for (int ks = 1; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s, 0, 0, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // 4 DS reads
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // 4 MFMAs
             // this lane's 16 keys of the block, relative to the reference
@@ -979,6 +981,8 @@ __global__ __launch_bounds__(WAVES * 64, 4) void attention_stream_kernel(AttnArg
                 const float delta = first ? mrow : (mrow > TAU ? mrow : 0.f);
                 const float sc = first ? 1.f : __builtin_amdgcn_exp2f(-delta);   // (first block: l and O are still zero)
                 m_ref += delta;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) negm[e] = -m_ref;
                 lsum *= sc;
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt)
