@@ -825,7 +825,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES * U == 8 ? 2 : 1) void attention_
 // the (sequence, head) items, two chunks ahead of the arithmetic, one K piece and one V piece per wave and chunk; the next
 // item's Q rows are staged through LDS the same way.  K passes through once: the softmax is the online form (running
 // reference m per query row, P = 2^(s - m) with the accumulator started at -m; m is only raised, exactly, when a block's
-// maximum exceeds it by more than 2^8 -- then l and O are rescaled -- so P <= 256 and the common step has no rescale).
+// maximum exceeds it by more than TAU = 40 (in the log2 domain) -- then l and O are rescaled -- so P <= 2^40 and the common step has
+// no rescale).
 //   WAVES = 16: sequences of 257..512 rows, chunks of 128 keys, 160 KiB of LDS, one workgroup per CU;
 //   WAVES = 8 : up to 256 rows, chunks of 64 keys, 80 KiB, two workgroups per CU.
 // Index algebra, LDS images of a K row block and of a V piece: as in attention_kernel.  vmcnt is in order; every wave
@@ -846,7 +847,11 @@ __global__ __launch_bounds__(WAVES * 64, 4) void attention_stream_kernel(AttnArg
     constexpr int NS = 3;                        // ring stages: the stream runs NS - 1 chunks ahead
     constexpr int STAGE = CHUNK * 256;           // bytes: K rows (CHUNK x 128) | V pieces (CHUNK x 128)
     constexpr int QBYTES = WAVES * 32 * 128;     // the item's Q rows
-    constexpr float TAU = 8.0f;
+    // How far a score may exceed the reference before the reference is moved.  P = 2^(s - m) <= 2^TAU is held in bf16 (8-bit
+    // exponent) and summed in fp32: 512 keys x 2^40 x |v| stays far inside the range, the relative precision of P does not depend
+    // on its scale, and a row's first block always contains P = 1 -- so a generous margin costs nothing and makes the rescale a
+    // rare event on any realistic logits (with 8 it ran on most steps once the logits' standard deviation reached ~5).
+    constexpr float TAU = 40.0f;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *const ring = smem + QBYTES;
     const int lane = threadIdx.x & 63;
