@@ -633,14 +633,17 @@ struct AttnArgs {
     int cls_only;        // last layer: only the query block holding <s> is needed (models.py:56 takes [:,0])
 };
 
-// Workgroup = WAVES waves = ALL query rows of one (sequence, head); a wave owns two 32-row query blocks,
-// so every K and V fragment feeds two MFMAs.  Both the head's K (len32 x 64) and V (64 x len32) live in
+// The two-pass attention kernel of round 1, kept behind hac_encoder_set_option("attn", "twopass") as the tests' cross-check of
+// the streaming kernel below (exact row maxima first, one workgroup per item).
+// Workgroup = WAVES waves = ALL query rows of one (sequence, head); a wave owns U 32-row query blocks (instantiated with
+// U = 1: four waves per SIMD hide more latency than sharing each K and V fragment between two MFMAs saves, -7 %).
+// Both the head's K (len32 x 64) and V (64 x len32) live in
 // LDS for the whole workgroup (<= 128 KiB), brought in once by LDS-DMA:
 //   K image   row*128 + ((chunk ^ ((row>>1)&7)) << 4)           (the GEMM's XOR swizzle)
 //   V image   1-KiB pieces (16-key group G, d-tile t): lane l = 32*hh + r holds V[keys 16G+8hh..+7][d = 32t+r],
 //             i.e. a piece IS the A operand of one MFMA and one contiguous KiB of the v16 tensor.
-// Sequences of <= 256 rows take the 4-wave instantiation (<= 64 KiB: two workgroups per CU), longer
-// ones the 8-wave instantiation; both are launched over all sequences and a workgroup whose sequence
+// Sequences of <= 256 rows take the 8-wave instantiation (<= 64 KiB: two workgroups per CU), longer
+// ones the 16-wave instantiation; both are launched over all sequences and a workgroup whose sequence
 // belongs to the other class leaves at once.
 // History: with V^T fragments fetched per wave from L2 (8-byte loads at a row stride) the kernel ran at
 // the texture-address rate, 0.55 ms per layer at B=256, L=512, and 0.40 ms with those loads removed.
