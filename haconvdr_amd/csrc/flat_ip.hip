@@ -699,11 +699,23 @@ __global__ __launch_bounds__(256) void kth_select_kernel(const float *__restrict
         hist[tid] = 0;
         __syncthreads();
         const int shift = pass * 8;
+        // (scores of one query share their sign and most exponent bits: a thread counts runs of one bin locally instead of
+        // sending every element to the same LDS counter)
+        u32 run_bin = 0, run = 0;
         for (u32 i = tid; i < S; i += 256) {
             const float v = src[i];
             const u32 key = (v != v) ? 0u : f2ord(v + 0.0f);
-            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+            if ((key & mask) == prefix) {
+                const u32 b = (key >> shift) & 255u;
+                if (b != run_bin && run) {
+                    atomicAdd(&hist[run_bin], run);
+                    run = 0;
+                }
+                run_bin = b;
+                ++run;
+            }
         }
+        if (run) atomicAdd(&hist[run_bin], run);
         __syncthreads();
         {   // bin b holds the kk-th largest key iff  above(b) < kk <= above(b) + hist[b],  above(b) = sum of bins > b.
             // Parallel suffix sum over the 256 bins (one per thread): wave scan + cross-wave offsets.
@@ -865,6 +877,7 @@ struct DeviceIndex {
         int scanq_nt = 0;        // 0: chosen by padding; 1..4 pins the query tiles per workgroup
         int scanq_waves = 8;
         bool no_p8 = false;
+        int seed_groups_max = 0;         // cap of the seeding pass of the prefilter scan, in 64-row groups; 0 = 14 sqrt(groups)
     } tune;
     void read_env() {
         if (const char *e = getenv("HAC_SPLIT")) tune.split = e[0] == '0' ? 0 : (e[0] == '1' ? 1 : -1);
@@ -882,6 +895,7 @@ struct DeviceIndex {
         else if (n == "scanq_nt") tune.scanq_nt = atoi(v.c_str());
         else if (n == "scanq_waves") tune.scanq_waves = v == "4" ? 4 : 8;
         else if (n == "scan_no_p8") tune.no_p8 = v == "1";
+        else if (n == "seed_groups_max") tune.seed_groups_max = atoi(v.c_str()) <= 0 ? 0 : std::max(768, atoi(v.c_str()));
         else return fail(HAC_ERR_INVALID, "unknown index option '%s'", name);
         return HAC_OK;
     }
@@ -1435,13 +1449,16 @@ struct DeviceIndex {
                 }
                 HAC_HIP(hipEventRecord(ev_pool[ev_used].first, st));
             }
-            // Seeding pass: the first sixteenth of the corpus (at least ~48k rows) is scored once just for its
-            // per-quarter maxima; their K2-th largest opens the real pass over ALL rows with thresholds that only
-            // ~K2 * 16 rows per query pass.  Without sharp opening thresholds list compactions (sorts) cost as
-            // much as half the MFMA work.
+            // Seeding pass: the head of the corpus is scored once just for its per-quarter maxima; their K2-th largest
+            // opens the real pass over ALL rows with thresholds that only ~K2 * G / GA rows per query pass.  Without sharp
+            // opening thresholds list compactions (sorts) cost as much as half the MFMA work; the seeding pass itself (and
+            // the selection over its 4 GA maxima per query) costs in proportion to GA: a sixteenth of the corpus up to
+            // 1M rows, then ~14 sqrt(G) groups (measured optimum at 6.75M / 10M / 25M rows: 4.1k / 5.1k / 10k groups;
+            // a sixteenth of 25M rows cost 1.5 ms more per 1000-query search, 2k groups 11 ms more).
             const dim3 grid((unsigned)P, (unsigned)n_qtiles), blk(SH_W * 64);
             const u32 round_groups = (u32)P * SH_GPR;
-            u32 GA = std::min<u32>(G, (std::max<u32>(G / 16u, 768u) + round_groups - 1u) / round_groups * round_groups);
+            const u32 seed_cap = tune.seed_groups_max > 0 ? (u32)tune.seed_groups_max : (u32)(14.0 * std::sqrt((double)G));
+            u32 GA = std::min<u32>(G, (std::max<u32>(std::min<u32>(G / 16u, seed_cap), 768u) + round_groups - 1u) / round_groups * round_groups);
             const float *thr_init = nullptr;
             if ((size_t)4 * GA >= (size_t)K2) {
                 const u32 S = 4u * GA;
