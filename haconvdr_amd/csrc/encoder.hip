@@ -114,15 +114,29 @@ __global__ __launch_bounds__(512) void seq_prep_kernel(const IT *__restrict__ id
     }
 }
 
-__global__ void seq_offsets_kernel(SeqInfo s, int B) {
-    // B is small (<= a few thousand): one thread does the exclusive scan
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        int acc = 0;
-        for (int b = 0; b < B; ++b) {
-            s.off[b] = acc;
-            acc += s.len32[b];
-        }
-        s.off[B] = acc;
+__global__ __launch_bounds__(256) void seq_offsets_kernel(SeqInfo s, int B) {
+    // exclusive scan of the padded lengths, one workgroup: every thread sums a run of consecutive sequences, the 256 run
+    // totals are scanned through LDS (a single thread walking 512 sequences took 0.11 ms per forward)
+    __shared__ int tot[256];
+    const int tid = threadIdx.x;
+    const int per = (B + 255) / 256, lo = min(B, tid * per), hi = min(B, lo + per);
+    int sum = 0;
+    for (int b = lo; b < hi; ++b) sum += s.len32[b];
+    tot[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const int v = tid >= o ? tot[tid - o] : 0;
+        __syncthreads();
+        tot[tid] += v;
+        __syncthreads();
+    }
+    int acc = tot[tid] - sum;
+    for (int b = lo; b < hi; ++b) {
+        s.off[b] = acc;
+        acc += s.len32[b];
+    }
+    if (tid == 255) {
+        s.off[B] = tot[255];
         *s.nb = B;
     }
 }
@@ -219,12 +233,12 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const IT *__restrict__ id
             v[i * 4 + 2] = (a.z + ty.z) + pp.z;
             v[i * 4 + 3] = (a.w + ty.w) + pp.w;
         }
-        ln768_store(v, gamma, beta, eps, lane, x_f32 + row * H, x_bf + row * H);
+        ln768_store(v, gamma, beta, eps, lane, x_f32 ? x_f32 + row * H : nullptr, x_bf + row * H);   // (no fp32 copy on the large-batch path: its residual stream is bf16)
     } else {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int c = i * 256 + lane * 4;
-            *reinterpret_cast<f4v *>(x_f32 + row * H + c) = (f4v){0.f, 0.f, 0.f, 0.f};
+            if (x_f32) *reinterpret_cast<f4v *>(x_f32 + row * H + c) = (f4v){0.f, 0.f, 0.f, 0.f};
             *reinterpret_cast<bf16x4 *>(x_bf + row * H + c) = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
         }
     }
@@ -235,7 +249,7 @@ __global__ __launch_bounds__(192) void zero_tail_rows_kernel(float *__restrict__
     const long row = (long)*total_rows + blockIdx.x;
     if (row >= Mp) return;
     const int c = threadIdx.x * 4;
-    *reinterpret_cast<f4v *>(x_f32 + row * H + c) = (f4v){0.f, 0.f, 0.f, 0.f};
+    if (x_f32) *reinterpret_cast<f4v *>(x_f32 + row * H + c) = (f4v){0.f, 0.f, 0.f, 0.f};
     *reinterpret_cast<bf16x4 *>(x_bf + row * H + c) = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
 }
 
@@ -1130,46 +1144,61 @@ __global__ __launch_bounds__(256) void gather_cls_kernel(const bf16 *__restrict_
 }
 
 // ------------------------------------------------------------------ ANCE head: out[b] = LN(W_h . x[row_b] + b_h)   (fp32)
-__global__ __launch_bounds__(256) void cls_head_kernel(const float *__restrict__ x, SeqInfo s, int compact, const float *__restrict__ Wh,
+constexpr int CLS_SB = 8;   // sequences per workgroup of the head: every row of W_h is read once per 8 sequences, not once per sequence
+__global__ __launch_bounds__(256) void cls_head_kernel(const float *__restrict__ x, SeqInfo s, int compact, int B, const float *__restrict__ Wh,
                                                        const float *__restrict__ bh, const float *__restrict__ gamma,
                                                        const float *__restrict__ beta, float eps, float *__restrict__ out) {
-    __shared__ float xs[H];
-    __shared__ float es[H];
+    __shared__ float xs[CLS_SB][H];
+    __shared__ float es[CLS_SB][H];
     __shared__ float red[8];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const float *xr = x + (size_t)(compact ? b : s.off[b]) * H;
-    for (int i = tid; i < H; i += 256) xs[i] = xr[i];
+    const int b0 = blockIdx.x * CLS_SB, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nb = min(CLS_SB, B - b0);
+    for (int j = 0; j < CLS_SB; ++j) {
+        const float *xr = x + (size_t)(compact ? b0 + j : s.off[min(b0 + j, B - 1)]) * H;
+        for (int i = tid; i < H; i += 256) xs[j][i] = j < nb ? xr[i] : 0.f;
+    }
     __syncthreads();
-    const bool bad = s.err[b] != 0;
-    // each wave computes 192 outputs; a wave reads one weight row at a time (coalesced) and reduces
+    // each wave computes 192 outputs per sequence; a wave reads one weight row at a time (coalesced) and reduces.  The
+    // arithmetic of a sequence (products, their order, the reduction) does not depend on its neighbours.
     for (int n = w; n < H; n += 4) {
         const float *wr = Wh + (size_t)n * H;
-        float acc = 0.f;
+        float wv[12];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) acc = fmaf(wr[lane + 64 * i], xs[lane + 64 * i], acc);
-        acc = wave_sum(acc);
-        if (lane == 0) es[n] = acc + bh[n];
+        for (int i = 0; i < 12; ++i) wv[i] = wr[lane + 64 * i];
+        const float bias = bh[n];
+#pragma unroll
+        for (int j = 0; j < CLS_SB; ++j) {
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) acc = fmaf(wv[i], xs[j][lane + 64 * i], acc);
+            acc = wave_sum(acc);
+            if (lane == 0) es[j][n] = acc + bias;
+        }
     }
     __syncthreads();
-    float sum = 0.f;
-    for (int i = tid; i < H; i += 256) sum += es[i];
-    sum = wave_sum(sum);
-    if (lane == 0) red[w] = sum;
-    __syncthreads();
-    const float mean = (red[0] + red[1] + red[2] + red[3]) * (1.0f / H);
-    float q = 0.f;
-    for (int i = tid; i < H; i += 256) {
-        const float d = es[i] - mean;
-        q += d * d;
-    }
-    q = wave_sum(q);
-    __syncthreads();
-    if (lane == 0) red[4 + w] = q;
-    __syncthreads();
-    const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) * (1.0f / H) + eps);
-    for (int i = tid; i < H; i += 256) {
-        const float v = (es[i] - mean) * rstd * gamma[i] + beta[i];
-        out[(size_t)b * H + i] = bad ? NAN : v;  // unsupported mask or token id of THIS sequence: fail loudly, never guess
+    for (int j = 0; j < nb; ++j) {
+        const int b = b0 + j;
+        float sum = 0.f;
+        for (int i = tid; i < H; i += 256) sum += es[j][i];
+        sum = wave_sum(sum);
+        if (lane == 0) red[w] = sum;
+        __syncthreads();
+        const float mean = (red[0] + red[1] + red[2] + red[3]) * (1.0f / H);
+        float q = 0.f;
+        for (int i = tid; i < H; i += 256) {
+            const float d = es[j][i] - mean;
+            q += d * d;
+        }
+        q = wave_sum(q);
+        if (lane == 0) red[4 + w] = q;
+        __syncthreads();
+        const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) * (1.0f / H) + eps);
+        const bool bad = s.err[b] != 0;
+        for (int i = tid; i < H; i += 256) {
+            const float v = (es[j][i] - mean) * rstd * gamma[i] + beta[i];
+            out[(size_t)b * H + i] = bad ? NAN : v;  // unsupported mask or token id of THIS sequence: fail loudly, never guess
+        }
+        __syncthreads();
     }
 }
 
@@ -1305,22 +1334,23 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
     SeqInfo s;
     HAC_TRY(seq_layout(e, B, L, s));
     seq_prep_kernel<IT><<<dim3(B), dim3(512), 0, st>>>(ids, mask, L, s, c.pad_token_id, c.vocab);
-    seq_offsets_kernel<<<dim3(1), dim3(64), 0, st>>>(s, B);
+    seq_offsets_kernel<<<dim3(1), dim3(256), 0, st>>>(s, B);
     attn_order_kernel<<<dim3(1), dim3(256), 0, st>>>(s, B);
     float *x = (float *)e->ws_x.p, *y = (float *)e->ws_y.p;
     float2 *statsA = (float2 *)e->ws_stats.p, *statsF = statsA + Mp;
     bf16 *xb = (bf16 *)e->ws_xb.p, *q = (bf16 *)e->ws_q.p, *k = (bf16 *)e->ws_k.p, *vt = (bf16 *)e->ws_vt.p;
     bf16 *ctx = (bf16 *)e->ws_ctx.p, *h = (bf16 *)e->ws_h.p;
-    embed_ln_kernel<IT><<<dim3(L32 / 4, B), dim3(256), 0, st>>>(ids, L, s, e->word, e->posw, e->typew, e->embg, e->embb, c.ln_eps, c.vocab, x, xb);
-    HAC_HIP(hipGetLastError());
-    const int *total = s.off + B;
-    // dead tail rows of the last M tile (fewer than MT) feed the GEMMs: keep them finite
-    zero_tail_rows_kernel<<<dim3(MT), dim3(192), 0, st>>>(x, xb, total, Mp);
-    HAC_HIP(hipGetLastError());
     // tile choice: 256^2 tiles once they fill the chip, 128^2 tiles for small batches; persistent grids
     const bool big = (Mp / 256) * (H / 256) >= 128;
     // large batches: the ping-pong GEMM with the LayerNorms folded into the consuming weights (gemm8.inc)
     const bool g8 = e->gemm_mode == 1 || (e->gemm_mode < 0 && big);
+    // (that path's residual stream is bf16 from the embedding rows on: no fp32 copy of them, 3 KB per token less to write)
+    embed_ln_kernel<IT><<<dim3(L32 / 4, B), dim3(256), 0, st>>>(ids, L, s, e->word, e->posw, e->typew, e->embg, e->embb, c.ln_eps, c.vocab, g8 ? nullptr : x, xb);
+    HAC_HIP(hipGetLastError());
+    const int *total = s.off + B;
+    // dead tail rows of the last M tile (fewer than MT) feed the GEMMs: keep them finite
+    zero_tail_rows_kernel<<<dim3(MT), dim3(192), 0, st>>>(g8 ? nullptr : x, xb, total, Mp);
+    HAC_HIP(hipGetLastError());
     const int bt = big ? 256 : 128;
     const size_t lds = (size_t)4 * bt * 128 + (size_t)(big ? 8 : 4) * 4096;   // 2 stages + per-wave patches
     const dim3 blk(big ? 512 : 256);
@@ -1458,7 +1488,7 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
     }
 #undef HAC_GEMM
     HAC_TRY(prof_end(e, 0, st));
-    cls_head_kernel<<<dim3(B), dim3(256), 0, st>>>(x_c, s, 1, e->wh, e->bh, e->ng, e->nb, 1e-5f, out_dev);
+    cls_head_kernel<<<dim3((unsigned)((B + CLS_SB - 1) / CLS_SB)), dim3(256), 0, st>>>(x_c, s, 1, B, e->wh, e->bh, e->ng, e->nb, 1e-5f, out_dev);
     HAC_HIP(hipGetLastError());
     return HAC_OK;
 }
