@@ -212,3 +212,22 @@ def test_large_batch_gemm_kernels_keep_everything_in_registers():
         assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1)) == 0, b[:200]
         assert int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1)) == 2
     assert seen == 3
+
+
+def test_streaming_attention_kernels_keep_everything_in_registers():
+    """attention_stream_kernel runs four waves per SIMD (128 VGPRs) behind a counted LDS-DMA stream: no spill, no scratch
+    (a scratch reload is a vmcnt(0), i.e. a drain of the K/V ring), and the occupancy its LDS budget was sized for."""
+    path = os.path.join(ROOT, "haconvdr_amd", "csrc", "encoder.resources.txt")
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(path)])
+    blocks = re.split(r"remark: Function Name: ", open(path).read())
+    seen = 0
+    for b in blocks:
+        if "attention_stream_kernel" not in b.split("\n", 1)[0]:
+            continue
+        seen += 1
+        assert int(re.search(r"VGPRs: (\d+)", b).group(1)) <= 128
+        assert int(re.search(r"VGPRs Spill: (\d+)", b).group(1)) == 0, b[:200]
+        assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1)) == 0, b[:200]
+        assert int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1)) == 4
+    assert seen == 2
