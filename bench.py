@@ -53,6 +53,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the headline step (profiling runs)")
     ap.add_argument("--search-only", action="store_true", help="BASELINE configs[1] style: pre-encoded embeddings, no encoder in the step")
+    ap.add_argument("--dump-results", default=None, metavar="NPZ",
+                    help="rank 0 writes the last timed step's query embeddings and merged (D, I) to this .npz (tests)")
     ap.add_argument("--spawn-selftest", type=int, default=None, metavar="RC",
                     help="tests only: every rank prints its RANK/WORLD_SIZE and exits (rank 1 with code RC); nothing touches a GPU")
     return ap.parse_args(argv)
@@ -61,7 +63,9 @@ def parse_args(argv=None):
 # ------------------------------------------------------------------------------ N > 1 without a launcher
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N`: start the N ranks as child processes (one per GPU), wait, and fail if any fails.
-    Runs before torch.cuda / HIP is initialised in this process; torch.cuda.device_count() does not initialise it."""
+    The parent never launches GPU work and never exec's: whatever torch.cuda.device_count() does to count the devices
+    (amdsmi where present, else hipGetDeviceCount, which does initialise the runtime), the ranks are fresh child
+    processes started with Popen."""
     if "--spawn-selftest" not in argv:
         import torch
         have = torch.cuda.device_count()
@@ -216,14 +220,18 @@ def main():
     q_pre = gen_rows(0xBEEF, nq, dev)                                    # pre-encoded queries (search-only figures)
     allq = torch.empty((world * nq_loc, D_EMB), dtype=torch.float32, device=dev) if world > 1 else None
 
+    last = {}
+
     def step(mask=None, srch=searcher):
         if enc is None:
             emb = q_pre
         else:
             emb = enc(ids_t, mask_t if mask is None else mask)
+            last["local_emb"] = emb
             if world > 1:
                 dist.all_gather_into_tensor(allq, emb)
                 emb = allq[:nq]
+        last["emb"] = emb
         return srch.search(emb, k)
 
     # ---- the timed region: W warm-up steps, then exactly K steps between barrier + synchronize ----------
@@ -242,6 +250,10 @@ def main():
     dt = max_over_ranks(time.perf_counter() - t0)
     scan_ms = index.profile_drain()
     plan = index.last_plan()
+    enc_plan = enc.last_plan() if enc is not None else None
+    timed_emb = last["local_emb"].clone() if enc is not None else None      # this rank's embeddings of the last timed step
+    if args.dump_results and rank == 0:
+        np.savez(args.dump_results, emb=last["emb"].cpu().numpy(), D=D.cpu().numpy(), I=I.cpu().numpy(), rows=rows, k=k, block_rows=block_rows)
     index.set_profiling(False)
     stack_ms, ffn_up_ms = [], []
     if enc is not None:
@@ -251,15 +263,10 @@ def main():
     value = nq * args.steps / dt
 
     # ---- rooflines (algorithmic figures of SURVEY.md §8d; kernel times = hipEvent brackets inside the timed region)
+    prof = load_profile_traffic()
+
     def pmc(name):
-        for rnd in ("r02", "r01"):
-            path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
-            if os.path.exists(path):
-                try:
-                    return json.load(open(path)).get(name)
-                except Exception:
-                    return None
-        return None
+        return None if prof["stale"] else prof["data"].get(name)
 
     scan_avg_ms = float(np.sum(scan_ms)) / args.steps if scan_ms else float("nan")
     s_bytes = n_local * D_EMB * 4 + nq * D_EMB * 4 + nq * k * 12
@@ -281,13 +288,16 @@ def main():
         search_roof = {"kernel": plan.split(" ")[0], "plan": plan, "bound": "hbm", "achieved": round(s_gbs, 1), "peak": PEAK_HBM_GBS,
                        "unit": "GB/s", "frac": round(s_gbs / PEAK_HBM_GBS, 4), "kernel_ms": round(scan_avg_ms, 4)}
     search_roof["traffic"] = pmc("search_hbm_bytes_per_launch") if (world == 1 and rows == CFG3_ROWS) else None
+    traffic_note = {"traffic_source": prof["note"]}
+    if prof["stale"]:
+        traffic_note["traffic_stale"] = prof["stale"]
 
     def mfma_util(needle):
         """Matrix-pipe busy share etc. of a kernel from the committed rocprofv3 SQ pass (profiles/r02_sq.*), same workload."""
         u = pmc("mfma_util") or {}
         for kname, v in u.items():
             if needle in kname and "short" not in kname:
-                return dict(v, source="profiles/r02_sq.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ... GRBM_GUI_ACTIVE pass of this bench)")
+                return dict(v, source=f"profiles/{prof['tag']}_sq.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ... GRBM_GUI_ACTIVE pass of this bench)")
         return None
     if world == 1 and rows == CFG3_ROWS:
         search_roof["mfma_util"] = mfma_util("scanh_kernel<1, false>")
@@ -311,9 +321,10 @@ def main():
                     "encoder_stack": {"ms_per_step": round(stack_avg, 3), "achieved_TFLOPs": round(enc_flops / (stack_avg * 1e-3) / 1e12, 1),
                                       "mfma_bf16_frac": round(enc_flops / (stack_avg * 1e-3) / 2.5e15, 4),
                                       "flops": "12 x (14,155,776 T + 4 T^2 768) + 2 x 768^2 per padded query, SURVEY 8d"},
-                    "search": search_roof}
+                    "encoder_plan": enc_plan, "search": search_roof}
     else:
         roofline = search_roof
+    roofline.update(traffic_note)
 
     out = {
         "metric": "queries/sec (encode+top-100) over N-passage 768-d corpus; HBM GB/s vs peak" if enc is not None
@@ -338,7 +349,8 @@ def main():
 
     # ---- CPU baseline (rank 0, N = 1): the oracle on the host cores, bounded sample of the same workload ----
     if want_cpu:
-        out["cpu_baseline"] = cpu_baseline(np, torch, synth, enc, D, I, q_pre, kept, rows, nq, k, Lq, tok if enc is not None else None)
+        out["cpu_baseline"] = cpu_baseline(np, torch, synth, enc, D, I, q_pre, kept, rows, nq, k, Lq, tok if enc is not None else None,
+                                           timed_emb.cpu().numpy() if timed_emb is not None else None, enc_plan)
     kept = None
 
     if not args.no_extras:
@@ -420,17 +432,57 @@ def main():
         dist.destroy_process_group()
 
 
+# ------------------------------------------------------------------------------ committed PMC passes (roofline.traffic)
+KERNEL_SOURCES = ("flat_ip.hip", "scan_split.inc", "encoder.hip", "gemm8.inc")
+
+
+def kernel_sources_sha256():
+    """One digest over the four kernel sources of the running tree (what tools/refresh_profiles.py stamps a campaign with)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "haconvdr_amd", "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
+def load_profile_traffic():
+    """The newest committed profiles/rNN_pmc_traffic.json (HBM bytes per launch and matrix-pipe busy share from separate
+    rocprofv3 --pmc passes of this bench, tools/profile_round.sh).  Those numbers belong to the kernels they were measured
+    on: the campaign is stamped with the digest of the kernel sources, and when the running tree's differs the line
+    carries traffic = null and says why instead of quoting another kernel's counters."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")), reverse=True)
+    if not paths:
+        return {"data": {}, "tag": None, "stale": "no committed PMC pass", "note": "none"}
+    tag = os.path.basename(paths[0])[:3]
+    try:
+        data = json.load(open(paths[0]))
+    except Exception as ex:
+        return {"data": {}, "tag": tag, "stale": f"{paths[0]}: {ex!r}", "note": "none"}
+    have, now = data.get("kernel_sources_sha256"), kernel_sources_sha256()
+    note = (f"profiles/{tag}_pmc_traffic.json: separate rocprofv3 --pmc passes of this bench (FETCH_SIZE x 1024 x 2, WRITE_SIZE x 1024), "
+            f"git {data.get('git_head', '?')}, kernel sources {str(have)[:12]}")
+    stale = None
+    if have != now:
+        stale = (f"the committed PMC passes ({tag}) were taken on kernel sources {str(have)[:12]}, this tree is {now[:12]}: "
+                 "traffic / mfma_util withheld until tools/profile_round.sh is re-run")
+    return {"data": data, "tag": tag, "stale": stale, "note": note}
+
+
 # ------------------------------------------------------------------------------ CPU baseline (SURVEY §8d)
 CPU_RESULT = {}   # the oracle's answer over the first 1M rows, checked against the GPU's in single_gpu_extras
 
 
-def cpu_baseline(np, torch, synth, enc, D, I, q_pre, kept, rows, nq, k, Lq, tok):
+def cpu_baseline(np, torch, synth, enc, D, I, q_pre, kept, rows, nq, k, Lq, tok, timed_emb=None, enc_plan=None):
     """The oracle on this box's host cores: C/OpenMP restatement of IndexFlatIP over a 1M-row slice of the corpus
     (x rows/1M to the full corpus: the scan is linear in rows) + the fp32 torch-CPU restatement of ANCE, each the
-    median of 5 runs after one warm-up.  faiss itself is tried first (the reference's CPU path, :52,:68-69)."""
+    median of 5 runs after one warm-up.  faiss itself is tried first (the reference's CPU path, :52,:68-69).
+    Thread counts are set through the libraries' own calls (an OMP_NUM_THREADS exported after libgomp has started does
+    nothing) and reported as used."""
     from oracle import ance_oracle, oracle
     cores = len(os.sched_getaffinity(0))
-    os.environ["OMP_NUM_THREADS"] = str(cores)
+    oracle.set_num_threads(cores)
     xh = np.concatenate(kept)[:1_000_000]
     n_slice = xh.shape[0]
     omp_threads = oracle.num_threads()
@@ -450,7 +502,8 @@ def cpu_baseline(np, torch, synth, enc, D, I, q_pre, kept, rows, nq, k, Lq, tok)
         ts.append(time.perf_counter() - tp)
     t_search_q = float(np.median(ts)) / nq_s * (rows / n_slice)
     search = {"queries_per_sec_over_slice": round(nq_s / float(np.median(ts)), 2), "slice_rows": n_slice, "queries": nq_s,
-              "runs_s": [round(t, 3) for t in ts], "threads": omp_threads}
+              "runs_s": [round(t, 3) for t in ts], "threads": omp_threads,
+              "decomposition": "(8-query block, row chunk) tasks over all threads; chunk lists merged in the canonical order"}
     CPU_RESULT["slice"] = (oD, oI)
     if faiss is not None:
         fi = faiss.IndexFlatIP(D_EMB)
@@ -465,12 +518,12 @@ def cpu_baseline(np, torch, synth, enc, D, I, q_pre, kept, rows, nq, k, Lq, tok)
     res = {"unit": "queries/s", "kind": "port", "cores": cores, "faiss": faiss_note, "search": search}
     if enc is None:
         res["value"] = round(1.0 / t_search_q, 3)
-        res["sample"] = (f"search only: {nq_s} queries over a {n_slice}-row slice, oracle/flat_ip_oracle.c (OpenMP, AVX2 fmaf chain), "
-                         f"median of 5, scaled x{rows / n_slice:g} to the {rows}-row corpus")
+        res["sample"] = (f"search only: {nq_s} queries over a {n_slice}-row slice, oracle/flat_ip_oracle.c (OpenMP, {omp_threads} threads, AVX2 fmaf "
+                         f"chain), median of 5, scaled x{rows / n_slice:g} to the {rows}-row corpus")
         return res
     # encode: fp32 torch CPU ops; thread count = the faster of all cores and 64 (one probe each)
     sd_cpu = synth.ance_state_dict(0xA11CE, 12, rich=False)
-    n_s = 4
+    n_s = 8
     ids_s, mask_s = tok[:n_s].astype(np.int64), np.ones((n_s, Lq), np.int64)
     best = None
     for nt in sorted({cores, min(cores, 64)}):
@@ -490,12 +543,27 @@ def cpu_baseline(np, torch, synth, enc, D, I, q_pre, kept, rows, nq, k, Lq, tok)
     t_enc_q = float(np.median(te)) / n_s
     import torch as _t
     got = enc(_t.from_numpy(ids_s).cuda(), _t.from_numpy(mask_s).cuda()).cpu().numpy()
+    small_plan = enc.last_plan()
     cosd = 1.0 - (got * ref).sum(1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(ref, axis=1))
-    res["encode"] = {"queries_per_sec": round(1.0 / t_enc_q, 3), "queries": n_s, "seq_len": Lq, "threads": best[0],
-                     "runs_s": [round(t, 3) for t in te], "max_1_minus_cos_gpu_vs_cpu": float(cosd.max())}
+    res["encode"] = {"queries_per_sec": round(1.0 / t_enc_q, 3), "queries": n_s, "seq_len": Lq, "threads": torch.get_num_threads(),
+                     "runs_s": [round(t, 3) for t in te], "max_1_minus_cos_gpu_vs_cpu": float(cosd.max()),
+                     "max_1_minus_cos_gpu_vs_cpu_kernels": f"these {n_s} queries encoded on their own ({small_plan}): the small-batch kernel family, "
+                                                           "NOT the kernels the metric times; the timed batch is checked below"}
+    if timed_emb is not None:
+        # the path the metric is made of, checked where it is timed: rows of the timed 1000 x 512 batch itself (both
+        # sub-batches, tile borders) against the fp32 oracle on those very sequences
+        pick = sorted({i for i in (0, 255, 256, 511, 512, len(timed_emb) - 1) if 0 <= i < len(timed_emb)})
+        ref_t = ance_oracle.ance_forward(sd_cpu, tok[pick].astype(np.int64), np.ones((len(pick), Lq), np.int64))
+        got_t = timed_emb[pick]
+        cosd_t = 1.0 - (got_t * ref_t).sum(1) / (np.linalg.norm(got_t, axis=1) * np.linalg.norm(ref_t, axis=1))
+        res["encode"]["max_1_minus_cos_timed_batch_vs_cpu"] = float(cosd_t.max())
+        res["encode"]["timed_batch_check"] = {"rows": pick, "one_minus_cos": [float(v) for v in cosd_t], "kernels": enc_plan,
+                                              "what": "embeddings produced INSIDE the timed region (last timed step) vs oracle/ance_oracle.py on the same sequences; "
+                                                      "bar 1e-3 (BASELINE.json north_star)"}
     res["value"] = round(1.0 / (t_enc_q + t_search_q), 3)
     res["cores"] = cores
-    res["sample"] = (f"encode: {n_s} of the {nq} queries (L={Lq}) through oracle/ance_oracle.py (fp32 torch CPU ops, {best[0]} threads); search: "
+    res["threads"] = {"search_openmp": omp_threads, "encode_torch": torch.get_num_threads()}
+    res["sample"] = (f"encode: {n_s} of the {nq} queries (L={Lq}) through oracle/ance_oracle.py (fp32 torch CPU ops, {torch.get_num_threads()} threads); search: "
                      f"{nq_s} queries over a {n_slice}-row slice through oracle/flat_ip_oracle.c (OpenMP, {omp_threads} threads), scaled "
                      f"x{rows / n_slice:g} to {rows} rows; each the median of 5 runs after a warm-up; value = 1 / (encode s/query + search s/query)")
     return res

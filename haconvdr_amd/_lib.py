@@ -53,6 +53,8 @@ def _declare(L):
     L.hac_encoder_forward.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.c_int, ctypes.c_int, c_f32p]
     L.hac_encoder_forward_device.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]
     L.hac_encoder_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_char_p]
+    L.hac_encoder_last_plan.argtypes = [vp]
+    L.hac_encoder_last_plan.restype = ctypes.c_char_p
     L.hac_encoder_set_profiling.argtypes = [vp, ctypes.c_int]
     L.hac_encoder_profile_drain.argtypes = [vp, c_f32p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
     L.hac_encoder_profile_drain_class.argtypes = [vp, ctypes.c_int, c_f32p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
@@ -74,7 +76,7 @@ EXPORTED_SYMBOLS = (
     "hac_index_reset", "hac_index_ntotal", "hac_index_set_option", "hac_index_set_profiling", "hac_index_profile_drain", "hac_index_last_plan",
     "hac_merge_keys_device", "hac_keys_to_results_device",
     "hac_encoder_create", "hac_encoder_destroy", "hac_encoder_set_weight", "hac_encoder_finalize", "hac_encoder_forward",
-    "hac_encoder_forward_device", "hac_encoder_set_option", "hac_encoder_set_profiling", "hac_encoder_profile_drain",
+    "hac_encoder_forward_device", "hac_encoder_set_option", "hac_encoder_last_plan", "hac_encoder_set_profiling", "hac_encoder_profile_drain",
     "hac_encoder_profile_drain_class",
 )
 

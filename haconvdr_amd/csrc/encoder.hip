@@ -963,7 +963,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void attention_stream_kernel(AttnArg
     bool stored = false;   // this wave's 4 context stores are the youngest entries of its queue
     int c_stage = 0;
     bf16x8 qf[4];
-    for (int n_done = 0;; ++n_done) {
+    for ([[maybe_unused]] int n_done = 0;; ++n_done) {   // (read by the stamp macro only)
         ATTS_T(0);
         const int tn = next_item(t);
         const bool has_next = tn < n_items;
@@ -1257,6 +1257,11 @@ struct hac_encoder {
     } pools[1 + HAC_ENC_NCLASS];
     long max_tokens = 262144;  // packed rows per sub-batch (workspaces: ~4.5 GB; 131072 is 2 % slower, 524288 no faster)
     int n_cu = 256;
+    // what the most recent forward ran (hac_encoder_last_plan)
+    const char *plan_gemm = "none";
+    int plan_sub_batches = 0;
+    long plan_rows = 0;
+    char last_plan[160] = "none";
 };
 
 namespace {
@@ -1316,8 +1321,9 @@ int seq_layout(hac_encoder *e, int B, int L, SeqInfo &s) {
 
 // rows_hint: an upper bound of the packed rows of this sub-batch when the caller knows one (sum of its
 // sequences' padded lengths), 0 = every sequence may be full length
+// g8_call: the GEMM family of the whole hac_encoder_forward* call (-1: decide here, from this sub-batch's rows)
 template <typename IT>
-int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, float *out_dev, hipStream_t st, long rows_hint = 0) {
+int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, float *out_dev, hipStream_t st, long rows_hint = 0, int g8_call = -1) {
     const hac_encoder_config &c = e->cfg;
     const int L32 = (L + SEQ_ALIGN - 1) / SEQ_ALIGN * SEQ_ALIGN;
     const long rows_max = rows_hint > 0 ? std::min<long>(rows_hint, (long)B * L32) : (long)B * L32;
@@ -1342,8 +1348,10 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
     bf16 *ctx = (bf16 *)e->ws_ctx.p, *h = (bf16 *)e->ws_h.p;
     // tile choice: 256^2 tiles once they fill the chip, 128^2 tiles for small batches; persistent grids
     const bool big = (Mp / 256) * (H / 256) >= 128;
-    // large batches: the ping-pong GEMM with the LayerNorms folded into the consuming weights (gemm8.inc)
-    const bool g8 = e->gemm_mode == 1 || (e->gemm_mode < 0 && big);
+    // large batches: the ping-pong GEMM with the LayerNorms folded into the consuming weights (gemm8.inc).  The family is
+    // chosen ONCE per hac_encoder_forward* call, from the whole batch (forward_batched): a small tail sub-batch of a large
+    // forward runs the same kernels as the others, so a sequence's embedding does not depend on which sub-batch it fell into.
+    const bool g8 = g8_call >= 0 ? g8_call != 0 : (e->gemm_mode == 1 || (e->gemm_mode < 0 && big));
     // (that path's residual stream is bf16 from the embedding rows on: no fp32 copy of them, 3 KB per token less to write)
     embed_ln_kernel<IT><<<dim3(L32 / 4, B), dim3(256), 0, st>>>(ids, L, s, e->word, e->posw, e->typew, e->embg, e->embb, c.ln_eps, c.vocab, g8 ? nullptr : x, xb);
     HAC_HIP(hipGetLastError());
@@ -1490,12 +1498,17 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
     HAC_TRY(prof_end(e, 0, st));
     cls_head_kernel<<<dim3((unsigned)((B + CLS_SB - 1) / CLS_SB)), dim3(256), 0, st>>>(x_c, s, 1, B, e->wh, e->bh, e->ng, e->nb, 1e-5f, out_dev);
     HAC_HIP(hipGetLastError());
+    e->plan_sub_batches += 1;
+    e->plan_rows += Mp;
+    e->plan_gemm = g8 ? "gemm8" : (big ? "classic256" : "classic128");
     return HAC_OK;
 }
 
 template <typename IT>
 int forward_batched(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, float *out_dev, hipStream_t st) {
     const int L32 = (L + SEQ_ALIGN - 1) / SEQ_ALIGN * SEQ_ALIGN;
+    e->plan_sub_batches = 0;
+    e->plan_rows = 0;
     if ((long)B * L32 <= e->max_tokens) return run_forward<IT>(e, ids, mask, B, L, out_dev, st);
     // More rows than one pass holds if every sequence were full length: size the sub-batches by the REAL padded
     // lengths (one seq_prep over the whole batch and a B-int read-back), so that varlen batches fill the
@@ -1516,6 +1529,11 @@ int forward_batched(hac_encoder *e, const IT *ids, const IT *mask, int B, int L,
     HAC_HIP(hipMemcpyAsync(e->h_len, s.len32, (size_t)B * 4, hipMemcpyDeviceToHost, st));
     HAC_HIP(hipStreamSynchronize(st));
     const int *len32 = e->h_len;
+    // one GEMM family for the whole call: by the rows of the whole batch (at least one sub-batch is max_tokens rows long)
+    long rows_all = 0;
+    for (int b = 0; b < B; ++b) rows_all += std::min<long>(std::max(len32[b], SEQ_ALIGN), L32);
+    const long rows_first = std::min<long>(rows_all, e->max_tokens);
+    const int g8_call = (e->gemm_mode == 1 || (e->gemm_mode < 0 && ((rows_first + MT - 1) / MT) * (H / 256) >= 128)) ? 1 : 0;
     for (int b0 = 0; b0 < B;) {
         long rows = 0;
         int nb = 0;
@@ -1525,7 +1543,7 @@ int forward_batched(hac_encoder *e, const IT *ids, const IT *mask, int B, int L,
             rows += r;
             ++nb;
         }
-        HAC_TRY(run_forward<IT>(e, ids + (size_t)b0 * L, mask + (size_t)b0 * L, nb, L, out_dev + (size_t)b0 * H, st, rows));
+        HAC_TRY(run_forward<IT>(e, ids + (size_t)b0 * L, mask + (size_t)b0 * L, nb, L, out_dev + (size_t)b0 * H, st, rows, g8_call));
         b0 += nb;
     }
     return HAC_OK;
@@ -1568,7 +1586,14 @@ int hac_encoder_create(const hac_encoder_config *cfg, int device, hac_encoder **
     (void)hipFuncSetAttribute((const void *)gemm8_kernel<EPI8_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void *)gemm8_kernel<EPI8_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void *)gemm8_kernel<EPI8_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    if (const char *m = getenv("HAC_ENC_GEMM")) e->gemm_mode = m[0] == 'c' ? 0 : (m[0] == '8' ? 1 : -1);   // classic | 8phase | auto
+    if (const char *m = getenv("HAC_ENC_GEMM")) {   // classic | 8phase | auto
+        const std::string v(m);
+        if (v != "auto" && v != "classic" && v != "8phase") {
+            delete e;
+            return fail(HAC_ERR_INVALID, "HAC_ENC_GEMM = '%s': auto | classic | 8phase", m);
+        }
+        e->gemm_mode = v == "classic" ? 0 : (v == "8phase" ? 1 : -1);
+    }
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) e->n_cu = prop.multiProcessorCount;
@@ -1746,11 +1771,30 @@ int hac_encoder_forward(hac_encoder *e, const int32_t *ids, const int32_t *mask,
 int hac_encoder_set_option(hac_encoder *e, const char *name, const char *value) {
     if (!e || !name || !value) return fail(HAC_ERR_INVALID, "set_option: null argument");
     const std::string n(name), v(value);
-    if (n == "gemm") e->gemm_mode = v == "classic" ? 0 : (v == "8phase" ? 1 : -1);
-    else if (n == "attn") e->attn_mode = v == "twopass" ? 1 : 0;
-    else if (n == "max_tokens") e->max_tokens = std::max<long>(4096, atol(value));
-    else return fail(HAC_ERR_INVALID, "unknown encoder option '%s'", name);
+    // a value outside the documented set is an error, never a silent default (a mistyped value in a cross-check test would
+    // otherwise exercise the wrong kernels and still pass)
+    if (n == "gemm") {
+        if (v != "auto" && v != "classic" && v != "8phase") return fail(HAC_ERR_INVALID, "encoder option gemm = '%s': auto | classic | 8phase", value);
+        e->gemm_mode = v == "classic" ? 0 : (v == "8phase" ? 1 : -1);
+    } else if (n == "attn") {
+        if (v != "stream" && v != "twopass") return fail(HAC_ERR_INVALID, "encoder option attn = '%s': stream | twopass", value);
+        e->attn_mode = v == "twopass" ? 1 : 0;
+    } else if (n == "max_tokens") {
+        char *end = nullptr;
+        const long t = strtol(value, &end, 10);
+        if (end == value || *end || t < 4096) return fail(HAC_ERR_INVALID, "encoder option max_tokens = '%s': an integer >= 4096", value);
+        e->max_tokens = t;
+    } else {
+        return fail(HAC_ERR_INVALID, "unknown encoder option '%s'", name);
+    }
     return HAC_OK;
+}
+
+const char *hac_encoder_last_plan(hac_encoder *e) {
+    if (!e) return "none";
+    snprintf(e->last_plan, sizeof e->last_plan, "gemm=%s attn=%s sub_batches=%d rows=%ld", e->plan_gemm, e->attn_mode ? "twopass" : "stream",
+             e->plan_sub_batches, e->plan_rows);
+    return e->last_plan;
 }
 
 int hac_encoder_set_profiling(hac_encoder *e, int mask) {

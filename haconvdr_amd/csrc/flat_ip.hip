@@ -887,16 +887,44 @@ struct DeviceIndex {
         if (const char *e = getenv("HAC_SCANQ_WAVES")) tune.scanq_waves = e[0] == '4' ? 4 : 8;
         if (getenv("HAC_SCAN_NO_P8")) tune.no_p8 = true;
     }
+    // a value outside the documented set is an error, never a silent default (a mistyped value in a cross-check test
+    // would otherwise exercise the wrong kernels and still pass)
     int set_option(const char *name, const char *value) {
         const std::string n(name), v(value ? value : "");
-        if (n == "split") tune.split = v == "0" ? 0 : (v == "1" ? 1 : -1);
-        else if (n == "split_terms") tune.split_terms = v == "3" ? 3 : 1;
-        else if (n == "force_scan16") tune.force_scan16 = v == "1";
-        else if (n == "scanq_nt") tune.scanq_nt = atoi(v.c_str());
-        else if (n == "scanq_waves") tune.scanq_waves = v == "4" ? 4 : 8;
-        else if (n == "scan_no_p8") tune.no_p8 = v == "1";
-        else if (n == "seed_groups_max") tune.seed_groups_max = atoi(v.c_str()) <= 0 ? 0 : std::max(768, atoi(v.c_str()));
-        else return fail(HAC_ERR_INVALID, "unknown index option '%s'", name);
+        auto one_of = [&](std::initializer_list<const char *> allowed) {
+            for (const char *a : allowed)
+                if (v == a) return true;
+            std::string list;
+            for (const char *a : allowed) list += std::string(list.empty() ? "" : " | ") + a;
+            (void)fail(HAC_ERR_INVALID, "index option %s = '%s': %s", name, v.c_str(), list.c_str());
+            return false;
+        };
+        if (n == "split") {
+            if (!one_of({"0", "1", "auto"})) return HAC_ERR_INVALID;
+            tune.split = v == "0" ? 0 : (v == "1" ? 1 : -1);
+        } else if (n == "split_terms") {
+            if (!one_of({"1", "3"})) return HAC_ERR_INVALID;
+            tune.split_terms = v == "3" ? 3 : 1;
+        } else if (n == "force_scan16") {
+            if (!one_of({"0", "1"})) return HAC_ERR_INVALID;
+            tune.force_scan16 = v == "1";
+        } else if (n == "scanq_nt") {
+            if (!one_of({"0", "1", "2", "3", "4"})) return HAC_ERR_INVALID;
+            tune.scanq_nt = atoi(v.c_str());
+        } else if (n == "scanq_waves") {
+            if (!one_of({"4", "8"})) return HAC_ERR_INVALID;
+            tune.scanq_waves = v == "4" ? 4 : 8;
+        } else if (n == "scan_no_p8") {
+            if (!one_of({"0", "1"})) return HAC_ERR_INVALID;
+            tune.no_p8 = v == "1";
+        } else if (n == "seed_groups_max") {
+            char *end = nullptr;
+            const long t = strtol(v.c_str(), &end, 10);
+            if (v.empty() || *end || t < 0) return fail(HAC_ERR_INVALID, "index option seed_groups_max = '%s': an integer >= 0 (0 = 14 sqrt(groups))", v.c_str());
+            tune.seed_groups_max = t <= 0 ? 0 : (int)std::max<long>(768, std::min<long>(t, 1 << 30));
+        } else {
+            return fail(HAC_ERR_INVALID, "unknown index option '%s'", name);
+        }
         return HAC_OK;
     }
     GrowBuf ws_partial, ws_pcnt, ws_seedkeys, ws_thr, ws_thrglob, ws_q, ws_qt, ws_keys, ws_D, ws_I, ws_stage[2];

@@ -129,6 +129,10 @@ class ANCEEncoder:
         """Tuning / test switch of this handle (include/haconvdr.h: hac_encoder_set_option), e.g. ("gemm", "classic")."""
         _lib.check(_lib.lib().hac_encoder_set_option(self._h, str(name).encode(), str(value).encode()))
 
+    def last_plan(self):
+        """Kernel families of the most recent forward: "gemm=gemm8|classic256|classic128 attn=... sub_batches=N rows=R"."""
+        return _lib.lib().hac_encoder_last_plan(self._h).decode()
+
     KERNEL_CLASSES = ("qkv", "attention", "out_proj", "ffn_up", "ffn_down", "layernorm")   # HAC_ENC_CLASS_* of include/haconvdr.h
 
     def set_profiling(self, on=True, classes=()):

@@ -19,11 +19,19 @@ import numpy as np
 logger = logging.getLogger(__name__)
 
 
-def _pids_of(offset2pid, offsets):
-    """passage ids of a row of corpus offsets; offset2pid is whatever the pickle held (list, ndarray or dict)."""
-    if isinstance(offset2pid, dict):
-        return [offset2pid[int(o)] for o in offsets]
-    table = offset2pid if isinstance(offset2pid, np.ndarray) else np.asarray(offset2pid)
+def _pid_table(offset2pid):
+    """offset2pid as the pickle held it (gen_tokenized_doc.py writes a plain python list: 25M entries for TopiOCQA, 54M for
+    QReCC; a dict or an ndarray are accepted too) -> something cheap to index many times.  The list is converted ONCE per
+    run, not once per query row."""
+    if isinstance(offset2pid, (dict, np.ndarray)):
+        return offset2pid
+    return np.asarray(offset2pid)
+
+
+def _pids_of(table, offsets):
+    """passage ids of a row of corpus offsets (table from _pid_table)."""
+    if isinstance(table, dict):
+        return [table[int(o)] for o in offsets]
     return table[np.asarray(offsets, dtype=np.int64)].tolist()
 
 
@@ -34,9 +42,10 @@ def output_test_res(query_embedding2id, retrieved_scores_mat, retrieved_pid_mat,
     its first occurrence made and inherits the rest.  One line per rank: qid Q0 pid rank 200-rank score ance."""
     k = args.top_k
     ranking = {}                                              # qid -> k (pid, score) slots, in first-seen order of the qids
+    table = _pid_table(offset2pid)
     for row in range(len(retrieved_pid_mat)):
         scores = retrieved_scores_mat[row][:k].tolist()       # python floats: their repr is what lands in the file
-        pids = _pids_of(offset2pid, retrieved_pid_mat[row][:k])
+        pids = _pids_of(table, retrieved_pid_mat[row][:k])
         first = np.sort(np.unique(np.asarray(pids), return_index=True)[1])
         slots = ranking.setdefault(query_embedding2id[row], [(0, 0)] * k)
         slots[:len(first)] = [(pids[i], scores[i]) for i in first]
@@ -63,11 +72,15 @@ def print_trec_res(run_file, qrel_file, rel_threshold=1):
     The run's score column is the integer ``200 - rank`` the reference parses (``int(line[4])``, :319).
     Definitions (trec_eval): recip_rank = 1 / rank of the first relevant document (0 if none);
     recall_k = relevant documents among the first k / relevant documents judged; ndcg_cut_3 = DCG@3 / ideal
-    DCG@3 with gain = the graded judgement and discount log2(rank + 1)."""
+    DCG@3 with gain = the graded judgement and discount log2(rank + 1).
+
+    Field separation: test_HAConvDR_topiocqa.py splits on single blanks (``split(" ")``, :299,:318), test_HAConvDR_qrecc.py on
+    any whitespace (``split()``; its default qrel file is the tab-separated qrecc_qrel.tsv, :395).  ``split()`` reads both:
+    on a single-blank-separated line it yields the same fields (the last one without its newline, which int() ignores)."""
     qrels, qrels_ndcg, runs = {}, {}, {}
     with open(qrel_file) as f:
         for line in f:
-            line = line.split(" ")
+            line = line.split()
             if len(line) < 4:
                 continue
             query, passage, rel = line[0], line[2], int(line[3])
@@ -75,7 +88,7 @@ def print_trec_res(run_file, qrel_file, rel_threshold=1):
             qrels.setdefault(query, {})[passage] = 1 if rel >= rel_threshold else 0
     with open(run_file) as f:
         for line in f:
-            line = line.split(" ")
+            line = line.split()
             if len(line) < 5:
                 continue
             runs.setdefault(line[0], {})[line[2]] = int(line[4])

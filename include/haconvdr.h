@@ -62,8 +62,10 @@ typedef struct hac_index hac_index;
  * src/test_HAConvDR_topiocqa.py:52,55-66.  d must be a multiple of 32, <= HAC_MAX_D
  * (the reference fixes d = 768).  device_ids[0..n_dev) are HIP ordinals; with
  * n_dev > 1 the rows of every add() are split contiguously across the devices and
- * search() merges the per-device top-k (faiss IndexShards semantics, one host
- * thread).  The scalable path is one process per GPU (haconvdr_amd.sharded). */
+ * search() merges the per-device top-k (faiss IndexShards semantics; the devices are
+ * searched concurrently, one host thread per device, rows stay numbered by insertion
+ * order over the whole index).  The scalable path is one process per GPU
+ * (haconvdr_amd.sharded). */
 int hac_index_create(int d, const int *device_ids, int n_dev, hac_index **out);
 void hac_index_destroy(hac_index *idx);
 
@@ -106,7 +108,9 @@ int hac_index_reset(hac_index *idx);
 int64_t hac_index_ntotal(const hac_index *idx);
 
 /* Tuning and test switches of a live handle: "split" = "0" | "1" | "auto", "split_terms" = "1" | "3",
- * "force_scan16" = "0" | "1", "scanq_nt" = "0".."4", "scanq_waves" = "4" | "8", "scan_no_p8" = "0" | "1".
+ * "force_scan16" = "0" | "1", "scanq_nt" = "0".."4", "scanq_waves" = "4" | "8", "scan_no_p8" = "0" | "1",
+ * "seed_groups_max" = cap of the prefilter's seeding pass in 64-row groups (integer >= 0; 0 = 14 sqrt(groups)).
+ * Any other name or value is HAC_ERR_INVALID (never a silent default).
  * The HAC_<NAME> environment variables give the defaults and are read once, in hac_index_create. */
 int hac_index_set_option(hac_index *idx, const char *name, const char *value);
 
@@ -175,21 +179,27 @@ int hac_encoder_forward_device(hac_encoder *enc, const void *ids_dev, const void
  * kernels with separate LayerNorm passes) | "8phase" (the large-batch ping-pong kernel with folded LayerNorms whenever
  * the batch has a whole 256-row tile); "attn" = "stream" (persistent single-pass attention kernels, the default) |
  * "twopass" (one workgroup per (sequence, head), exact row maxima first: the cross-check of the tests);
- * "max_tokens" = packed rows per sub-batch.  HAC_ENC_GEMM gives the default of "gemm" and is read once, in
- * hac_encoder_create. */
+ * "max_tokens" = packed rows per sub-batch (integer >= 4096).  Any other name or value is HAC_ERR_INVALID (never a
+ * silent default).  HAC_ENC_GEMM gives the default of "gemm" and is read once, in hac_encoder_create.
+ * "auto" decides ONCE per forward call, from the rows of the whole batch: every sub-batch of a call runs the same
+ * GEMM family, so a sequence's embedding does not depend on the sub-batch it fell into. */
 int hac_encoder_set_option(hac_encoder *enc, const char *name, const char *value);
+/* What the most recent forward ran: "gemm=gemm8|classic256|classic128 attn=stream|twopass sub_batches=N rows=R"
+ * (tests and bench.py assert the kernel family they mean to check). */
+const char *hac_encoder_last_plan(hac_encoder *enc);
 
 /* Profiling aid for bench.py: hipEvent pairs recorded on the launch stream (no host sync).  mask bit 0:
  * around the layer stack of each forward (sub-batch); bit 1+c: around every launch of kernel class c.
  * hac_encoder_profile_drain / _drain_class wait for the recorded pairs, write up to cap durations (ms, in
  * launch order) and clear the record. */
 enum {
-    HAC_ENC_CLASS_QKV = 0,       /* gemm_bf16_nt_kernel<EPI_QKV>:   [T,768] x [2304,768]^T + bias, Q scale, V regrouping */
+    /* kernels: large batches gemm8_kernel<EPI8_*> (gemm8.inc), small ones gemm_bf16_nt_kernel<EPI_*> */
+    HAC_ENC_CLASS_QKV = 0,       /* <EPI8_QKV | EPI_QKV>:     [T,768] x [2304,768]^T (+ folded LayerNorm) + bias, Q scale, V regrouping */
     HAC_ENC_CLASS_ATTN = 1,      /* attention_stream_kernel<16|8> (both launches of a layer) */
-    HAC_ENC_CLASS_OUTPROJ = 2,   /* gemm_bf16_nt_kernel<EPI_RESID>: [T,768] x [768,768]^T + bias + residual (+ LayerNorm statistics) */
-    HAC_ENC_CLASS_FFN_UP = 3,    /* gemm_bf16_nt_kernel<EPI_GELU>:  [T,768] x [3072,768]^T + bias + erf GELU */
-    HAC_ENC_CLASS_FFN_DOWN = 4,  /* gemm_bf16_nt_kernel<EPI_RESID>: [T,3072] x [768,3072]^T + bias + residual (+ LayerNorm statistics) */
-    HAC_ENC_CLASS_LN = 5,        /* LayerNorm passes that are their own kernel */
+    HAC_ENC_CLASS_OUTPROJ = 2,   /* <EPI8_RESID | EPI_RESID>: [T,768] x [768,768]^T + bias + residual (+ LayerNorm statistics) */
+    HAC_ENC_CLASS_FFN_UP = 3,    /* <EPI8_GELU | EPI_GELU>:   [T,768] x [3072,768]^T (+ folded LayerNorm) + bias + erf GELU */
+    HAC_ENC_CLASS_FFN_DOWN = 4,  /* <EPI8_RESID | EPI_RESID>: [T,3072] x [768,3072]^T + bias + residual (+ LayerNorm statistics) */
+    HAC_ENC_CLASS_LN = 5,        /* LayerNorm passes that are their own kernel (ln_combine_kernel / ln_stats_rows_kernel) */
     HAC_ENC_NCLASS = 6
 };
 int hac_encoder_set_profiling(hac_encoder *enc, int mask);

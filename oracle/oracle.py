@@ -41,6 +41,8 @@ def lib():
         L.oracle_merge_step.argtypes = [f64p, i64p, f64p, i64p, ctypes.c_int64, ctypes.c_int, f64p, i64p]
         L.oracle_merge_step.restype = None
         L.oracle_num_threads.restype = ctypes.c_int
+        L.oracle_set_num_threads.argtypes = [ctypes.c_int]
+        L.oracle_set_num_threads.restype = None
         _LIB = L
     return _LIB
 
@@ -127,3 +129,8 @@ def search_one_by_one(blocks, q, topN):
 
 def num_threads():
     return int(lib().oracle_num_threads())
+
+
+def set_num_threads(n):
+    """OpenMP team size of later searches (setting OMP_NUM_THREADS after libgomp is up does nothing)."""
+    lib().oracle_set_num_threads(int(n))

@@ -1,0 +1,44 @@
+"""bench.py as the driver runs it, on the GPU box: the N > 1 control flow (ranks started by bench.py itself, shards,
+data-parallel encode, all-gather of embeddings and of packed top-k keys, on-device merge) rehearsed with two ranks sharing
+the one GPU of this pool's boxes (gloo; RCCL wants one device per rank), and the merged result of a step checked against a
+single-process search over the same rows.  Reference split: src/test_HAConvDR_topiocqa.py:55-66 (faiss shard=True)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_two_rank_rehearsal_matches_single_process(tmp_path):
+    import torch
+    dump = str(tmp_path / "step.npz")
+    env = dict(os.environ, HAC_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "2000000", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-extras", "--dump-results", dump]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    js = json.loads(lines[0])
+    assert js["n_gpus"] == 2 and js["steps"] == 2 and js["warmup"] == 1 and js["scaling"] == "weak" and "rehearsal" in js
+    assert js["config"]["corpus_rows"] == 2_000_000 and js["config"]["rows_per_gpu"] == 1_000_000
+    assert js["value"] > 0 and abs(js["value"] - 1000 / (js["ms_per_step"] * 1e-3)) < 1e-3 * js["value"]
+    g = np.load(dump)
+    assert g["emb"].shape == (1000, 768) and g["D"].shape == (1000, 100) and g["I"].shape == (1000, 100)
+    # the same 2M rows in ONE index, the same embeddings: the sharded step's merged result must be this, bit for bit
+    sys.path.insert(0, ROOT)
+    import bench
+    from haconvdr_amd.index import FlatIPIndex
+    dev = torch.device("cuda", 0)
+    idx = FlatIPIndex(768)
+    bench.fill_index(idx, 0, int(g["rows"]), dev, int(g["block_rows"]))
+    D, I = idx.search_tensor(torch.from_numpy(g["emb"]).to(dev), int(g["k"]))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(I.cpu().numpy(), g["I"])
+    np.testing.assert_array_equal(D.cpu().numpy(), g["D"])
+    assert int(g["I"].max()) >= 1_000_000 and int(g["I"].min()) < 1_000_000      # both shards contribute

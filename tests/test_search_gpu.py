@@ -508,6 +508,38 @@ def test_sharded_search_across_ranks_sharing_the_gpu(world, oracle, tmp_path):
     assert_same(got["D"], got["I"], *oracle.flat_ip_search(x, q, k))
 
 
+def test_sharded_search_rccl_one_gpu_per_rank(oracle, tmp_path):
+    """The same two-rank search with one GPU per rank and RCCL (backend "nccl") carrying both all-gathers: runs by itself
+    wherever at least two GPUs are visible (the 1-GPU boxes of this pool skip it; the driver's 8-GPU node does not)."""
+    import socket
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    world, n, nq, k = 2, 30011, 37, 100
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "rank0.npz")
+    script = os.path.join(os.path.dirname(__file__), "_sharded_gpu_rank.py")
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HAC_TEST_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, script, out, str(n), str(nq), str(k)], env=env))
+    try:
+        codes = [p.wait(timeout=300) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert codes == [0] * world
+    got = np.load(out)
+    x, q, _ = cases.search_case_inputs("dup", 0x5AAD, n, nq)
+    assert_same(got["D"], got["I"], *oracle.flat_ip_search(x, q, k))
+
+
 def test_resident_corpus_many_searches(tmp_path, oracle):
     """Blocks loaded once (zero-copy mmap of the pickled payload), searched repeatedly."""
     from haconvdr_amd.passages import write_embedding_block

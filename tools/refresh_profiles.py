@@ -13,7 +13,9 @@ back are then copied into profiles/)
   profiles/<tag>_pmc_fetch|write.{json,md}  FETCH_SIZE / WRITE_SIZE per launch (KiB; read bytes = KiB x 1024 x 2 on gfx950 for
                                             16-B/lane streaming reads, write bytes = KiB x 1024: MI355X_MICROARCH.md, HBM)
   profiles/<tag>_sq.{json,md}               SQ_* / GRBM per launch + derived: matrix-pipe busy share, wave-time split, clock
-  profiles/<tag>_pmc_traffic.json           what bench.py reads back: HBM bytes per launch of the dominant kernels, MFMA busy
+  profiles/<tag>_pmc_traffic.json           what bench.py reads back: HBM bytes per launch of the dominant kernels, MFMA busy;
+                                            stamped with the git HEAD (HAC_GIT_HEAD on the GPU box, which has no .git) and the
+                                            sha256 of the four kernel sources -- bench.py withholds the numbers when they differ
 """
 import glob
 import json
@@ -48,8 +50,18 @@ def main():
         shutil.copy(stats[0], pre + "kernel_stats.csv")
     if bench:
         shutil.copy(bench, pre + "bench.json")
-    out = {"source": f"profiles/{tag}_pmc_fetch.json, {tag}_pmc_write.json, {tag}_sq.json: separate rocprofv3 --pmc passes of "
-                     "`python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras` (tools/profile_round.sh)"}
+    sys.path.insert(0, ROOT)
+    import bench
+    head = os.environ.get("HAC_GIT_HEAD")
+    if not head:
+        try:
+            head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, check=True).stdout.strip()
+        except Exception:
+            head = "unknown (no .git on the GPU box: pass HAC_GIT_HEAD)"
+    out = {"git_head": head, "kernel_sources_sha256": bench.kernel_sources_sha256(), "kernel_sources": list(bench.KERNEL_SOURCES),
+           "source": f"profiles/{tag}_pmc_fetch.json, {tag}_pmc_write.json, {tag}_sq.json: separate rocprofv3 --pmc passes of "
+                     "`python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras` (tools/profile_round.sh); bench.py quotes these "
+                     "numbers only while the digest of the kernel sources of the running tree equals kernel_sources_sha256"}
 
     def load(name):
         p = pre + name + ".json"
