@@ -474,6 +474,27 @@ def load_profile_traffic():
 CPU_RESULT = {}   # the oracle's answer over the first 1M rows, checked against the GPU's in single_gpu_extras
 
 
+def host_cores():
+    """(logical CPUs this process may run on, CPUs' worth of time its cgroup grants).  The GPU boxes of this pool show 256
+    logical CPUs but cap a 1-GPU job at a share of them: 256 busy threads on a 16-CPU quota run slower than 16."""
+    affinity = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                       # cgroup v2: "<quota> <period>" or "max <period>"
+            a, b = f.read().split()[:2]
+            if a != "max":
+                quota = float(a) / float(b)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())  # cgroup v1
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    return affinity, quota
+
+
 def cpu_baseline(np, torch, synth, enc, D, I, q_pre, kept, rows, nq, k, Lq, tok, timed_emb=None, enc_plan=None):
     """The oracle on this box's host cores: C/OpenMP restatement of IndexFlatIP over a 1M-row slice of the corpus
     (x rows/1M to the full corpus: the scan is linear in rows) + the fp32 torch-CPU restatement of ANCE, each the
@@ -481,10 +502,19 @@ def cpu_baseline(np, torch, synth, enc, D, I, q_pre, kept, rows, nq, k, Lq, tok,
     Thread counts are set through the libraries' own calls (an OMP_NUM_THREADS exported after libgomp has started does
     nothing) and reported as used."""
     from oracle import ance_oracle, oracle
-    cores = len(os.sched_getaffinity(0))
-    oracle.set_num_threads(cores)
+    affinity, quota = host_cores()
+    cores = affinity if quota is None else max(1, min(affinity, int(quota + 0.5)))
     xh = np.concatenate(kept)[:1_000_000]
     n_slice = xh.shape[0]
+    # the team size that is fastest on this box: the granted CPUs, or every logical CPU (one probe each)
+    probe = {}
+    for nt in sorted({cores, affinity}):
+        oracle.set_num_threads(nt)
+        oracle.flat_ip_search(xh[:100_000], q_pre[:64].cpu().numpy(), k)
+        tp = time.perf_counter()
+        oracle.flat_ip_search(xh[:100_000], q_pre[:64].cpu().numpy(), k)
+        probe[nt] = time.perf_counter() - tp
+    oracle.set_num_threads(min(probe, key=probe.get))
     omp_threads = oracle.num_threads()
     try:
         import faiss  # noqa: F401
@@ -515,7 +545,7 @@ def cpu_baseline(np, torch, synth, enc, D, I, q_pre, kept, rows, nq, k, Lq, tok,
             fi.search(qh, k)
             tf.append(time.perf_counter() - tp)
         search["faiss_cpu_queries_per_sec_over_slice"] = round(nq_s / float(np.median(tf)), 2)
-    res = {"unit": "queries/s", "kind": "port", "cores": cores, "faiss": faiss_note, "search": search}
+    res = {"unit": "queries/s", "kind": "port", "cores": cores, "logical_cpus": affinity, "cgroup_cpu_quota": quota, "faiss": faiss_note, "search": search}
     if enc is None:
         res["value"] = round(1.0 / t_search_q, 3)
         res["sample"] = (f"search only: {nq_s} queries over a {n_slice}-row slice, oracle/flat_ip_oracle.c (OpenMP, {omp_threads} threads, AVX2 fmaf "
@@ -526,7 +556,7 @@ def cpu_baseline(np, torch, synth, enc, D, I, q_pre, kept, rows, nq, k, Lq, tok,
     n_s = 8
     ids_s, mask_s = tok[:n_s].astype(np.int64), np.ones((n_s, Lq), np.int64)
     best = None
-    for nt in sorted({cores, min(cores, 64)}):
+    for nt in sorted({cores, affinity, min(affinity, 64)}):
         torch.set_num_threads(nt)
         ance_oracle.ance_forward(sd_cpu, ids_s[:1], mask_s[:1])
         tp = time.perf_counter()
@@ -561,7 +591,7 @@ def cpu_baseline(np, torch, synth, enc, D, I, q_pre, kept, rows, nq, k, Lq, tok,
                                               "what": "embeddings produced INSIDE the timed region (last timed step) vs oracle/ance_oracle.py on the same sequences; "
                                                       "bar 1e-3 (BASELINE.json north_star)"}
     res["value"] = round(1.0 / (t_enc_q + t_search_q), 3)
-    res["cores"] = cores
+    res["cores"] = max(omp_threads, torch.get_num_threads())          # the threads actually used (the larger of the two legs)
     res["threads"] = {"search_openmp": omp_threads, "encode_torch": torch.get_num_threads()}
     res["sample"] = (f"encode: {n_s} of the {nq} queries (L={Lq}) through oracle/ance_oracle.py (fp32 torch CPU ops, {torch.get_num_threads()} threads); search: "
                      f"{nq_s} queries over a {n_slice}-row slice through oracle/flat_ip_oracle.c (OpenMP, {omp_threads} threads), scaled "

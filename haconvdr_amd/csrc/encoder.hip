@@ -1244,6 +1244,9 @@ struct hac_encoder {
     size_t idstats_rows = 0;
     int attn_mode = 0;                    // 0: streaming single-pass attention; 1: two-pass kernels (cross-check)
     int gemm_mode = -1;                   // -1: by size, 0: classic kernels only, 1: gemm8 whenever the batch has a full tile (tests)
+    // gemm8 loop form per class (bit 0 QKV, 1 out-proj, 2 FFN-up, 3 FFN-down; 1 = SPLIT).  A/B in one process on the 1000 x 512
+    // forward (tools/ab_encoder.py): SPLIT -1 % on QKV and -3.4 % on FFN-down (K = 3072), +3 % on out-proj, +1 % on FFN-up
+    int g8_split = 9;
     void *h_pin = nullptr;
     size_t h_pin_bytes = 0;
     int *h_len = nullptr;      // pinned: padded lengths of a forward that runs as several sub-batches
@@ -1405,14 +1408,22 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
         g8a.n_groups = 1;
         const int ng_up = 2;   // FFN-up: W1' is 4.7 MB against 4 MB of L2 per XCD; each XCD owns half of its column tiles (measured: -2 %)
         const dim3 grid8((unsigned)e->n_cu), blk8(512);
-        const size_t lds8 = 131072;
+        // gemm8.inc's two loop forms: SPLIT (operand-split DMA roles, 160 KiB) / round 2's (128 KiB); one bit of g8_split per class
+        auto launch8 = [&](auto epi, int cls_bit) {
+            constexpr int EPI = decltype(epi)::value;
+            if ((e->g8_split >> cls_bit) & 1) gemm8_kernel<EPI, true><<<grid8, blk8, 163840, st>>>(g8a);
+            else gemm8_kernel<EPI, false><<<grid8, blk8, 131072, st>>>(g8a);
+        };
+        constexpr std::integral_constant<int, EPI8_QKV> epi_qkv{};
+        constexpr std::integral_constant<int, EPI8_RESID> epi_resid{};
+        constexpr std::integral_constant<int, EPI8_GELU> epi_gelu{};
         // QKV
         if (g8) {
             // A = the previous layer's un-normalized output rows (bf16) + their statistics; layer 0: the normalized embedding rows
             HAC_TRY(prof_begin(e, 1 + HAC_ENC_CLASS_QKV, st));
             g8a.A = xb; g8a.K = H; g8a.astats = li ? statsF : idstats;
             g8a.W = w.wqkv8; g8a.N = 3 * H; g8a.wsum = w.fold; g8a.cvec = w.fold + 3 * H; g8a.q = q; g8a.k = k; g8a.v16 = vt;
-            gemm8_kernel<EPI8_QKV><<<grid8, blk8, lds8, st>>>(g8a);
+            launch8(epi_qkv, 0);
             HAC_TRY(prof_end(e, 1 + HAC_ENC_CLASS_QKV, st));
         } else {
             g.A = xb; g.W = w.wqkv; g.bias = w.bqkv; g.N = 3 * H; g.K = H; g.q = q; g.k = k; g.v16 = vt;
@@ -1439,7 +1450,7 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
             g8a.A = ctx; g8a.W = w.wo; g8a.N = H; g8a.K = H; g8a.cvec = w.bo; g8a.resid = xb; g8a.yb = yAb; g8a.part = part;
             g8a.rstats = defer_in ? statsF : nullptr; g8a.rgamma = ln2g_prev; g8a.rbeta = ln2b_prev;
             HAC_TRY(prof_begin(e, 1 + HAC_ENC_CLASS_OUTPROJ, st));
-            gemm8_kernel<EPI8_RESID><<<grid8, blk8, lds8, st>>>(g8a);
+            launch8(epi_resid, 1);
             HAC_TRY(prof_end(e, 1 + HAC_ENC_CLASS_OUTPROJ, st));
             HAC_TRY(prof_begin(e, 1 + HAC_ENC_CLASS_LN, st));
             ln_combine_kernel<<<dim3((unsigned)(Mp / 256)), dim3(256), 0, st>>>(part, H / 64, H, total, c.ln_eps, statsA);
@@ -1448,14 +1459,14 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
             g8a.A = yAb; g8a.astats = statsA; g8a.W = w.w18; g8a.N = FF; g8a.K = H; g8a.wsum = w.fold + 6 * H; g8a.cvec = w.fold + 6 * H + FF; g8a.h = h;
             g8a.n_groups = ng_up;
             HAC_TRY(prof_begin(e, 1 + HAC_ENC_CLASS_FFN_UP, st));
-            gemm8_kernel<EPI8_GELU><<<grid8, blk8, lds8, st>>>(g8a);
+            launch8(epi_gelu, 2);
             HAC_TRY(prof_end(e, 1 + HAC_ENC_CLASS_FFN_UP, st));
             g8a.n_groups = 1;
             // FFN down + residual LN1(yA) -> yF (bf16, in xb's buffer: the next layer's A operand and residual), partials
             g8a.A = h; g8a.W = w.w2; g8a.N = H; g8a.K = FF; g8a.cvec = w.b2; g8a.resid = yAb; g8a.yb = xb;
             g8a.rstats = statsA; g8a.rgamma = w.ln1g; g8a.rbeta = w.ln1b;
             HAC_TRY(prof_begin(e, 1 + HAC_ENC_CLASS_FFN_DOWN, st));
-            gemm8_kernel<EPI8_RESID><<<grid8, blk8, lds8, st>>>(g8a);
+            launch8(epi_resid, 3);
             HAC_TRY(prof_end(e, 1 + HAC_ENC_CLASS_FFN_DOWN, st));
             HAC_TRY(prof_begin(e, 1 + HAC_ENC_CLASS_LN, st));
             ln_combine_kernel<<<dim3((unsigned)(Mp / 256)), dim3(256), 0, st>>>(part, H / 64, H, total, c.ln_eps, statsF);
@@ -1583,9 +1594,12 @@ int hac_encoder_create(const hac_encoder_config *cfg, int device, hac_encoder **
     (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_QKV, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
     (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_RESID, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
     (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_GELU, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-    (void)hipFuncSetAttribute((const void *)gemm8_kernel<EPI8_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    (void)hipFuncSetAttribute((const void *)gemm8_kernel<EPI8_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    (void)hipFuncSetAttribute((const void *)gemm8_kernel<EPI8_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void *)gemm8_kernel<EPI8_QKV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    (void)hipFuncSetAttribute((const void *)gemm8_kernel<EPI8_QKV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void *)gemm8_kernel<EPI8_RESID, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    (void)hipFuncSetAttribute((const void *)gemm8_kernel<EPI8_RESID, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void *)gemm8_kernel<EPI8_GELU, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    (void)hipFuncSetAttribute((const void *)gemm8_kernel<EPI8_GELU, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     if (const char *m = getenv("HAC_ENC_GEMM")) {   // classic | 8phase | auto
         const std::string v(m);
         if (v != "auto" && v != "classic" && v != "8phase") {
@@ -1779,6 +1793,11 @@ int hac_encoder_set_option(hac_encoder *e, const char *name, const char *value) 
     } else if (n == "attn") {
         if (v != "stream" && v != "twopass") return fail(HAC_ERR_INVALID, "encoder option attn = '%s': stream | twopass", value);
         e->attn_mode = v == "twopass" ? 1 : 0;
+    } else if (n == "g8_split") {
+        char *end = nullptr;
+        const long t = strtol(value, &end, 10);
+        if (end == value || *end || t < 0 || t > 15) return fail(HAC_ERR_INVALID, "encoder option g8_split = '%s': a bit mask 0..15", value);
+        e->g8_split = (int)t;
     } else if (n == "max_tokens") {
         char *end = nullptr;
         const long t = strtol(value, &end, 10);

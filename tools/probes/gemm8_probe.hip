@@ -7,15 +7,23 @@
 #include <random>
 #define CK(x) do{hipError_t e_=(x); if(e_!=hipSuccess){printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} }while(0)
 using namespace hac;
-template <int EPI> float run(Gemm8Args g, int iters){
-  CK(hipFuncSetAttribute((const void*)gemm8_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+// SPLIT = true: the shipped form (operand-split DMA roles, 160 KiB); false: round 2's form (128 KiB).  Both in one process,
+// interleaved rounds (cdna_hip_programming.md 5.4 rule 24).
+template <int EPI, bool SPLIT> float run1(Gemm8Args g, int iters){
+  const size_t lds = SPLIT ? 163840 : 131072;
+  CK(hipFuncSetAttribute((const void*)gemm8_kernel<EPI, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipEvent_t e0,e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for(int i=0;i<2;i++) gemm8_kernel<EPI><<<256,512,131072>>>(g);
+  gemm8_kernel<EPI, SPLIT><<<256,512,lds>>>(g);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  for(int i=0;i<iters;i++) gemm8_kernel<EPI><<<256,512,131072>>>(g);
+  for(int i=0;i<iters;i++) gemm8_kernel<EPI, SPLIT><<<256,512,lds>>>(g);
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
-  float ms; CK(hipEventElapsedTime(&ms,e0,e1)); return ms/iters;
+  float ms; CK(hipEventElapsedTime(&ms,e0,e1)); CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1)); return ms/iters;
+}
+template <int EPI> float run(Gemm8Args g, int iters, float* t_old){
+  float best_new = 1e9f, best_old = 1e9f;
+  for (int r = 0; r < 4; ++r) { best_old = std::min(best_old, run1<EPI,false>(g, iters)); best_new = std::min(best_new, run1<EPI,true>(g, iters)); }
+  *t_old = best_old; return best_new;
 }
 int main(){
   const int M = 131072;
@@ -37,9 +45,32 @@ int main(){
   struct Cfg{const char* name; int N,K,epi;};
   Cfg cfgs[] = {{"QKV   N=2304 K=768 ",2304,768,EPI8_QKV},{"OUT   N=768  K=768 ",768,768,EPI8_RESID},{"FFN1  N=3072 K=768 ",3072,768,EPI8_GELU},{"FFN2  N=768  K=3072",768,3072,EPI8_RESID}};
   for(auto&c: cfgs){
-    g.N=c.N; g.K=c.K; float t=0;
-    if(c.epi==EPI8_QKV) t=run<EPI8_QKV>(g,5); if(c.epi==EPI8_RESID) t=run<EPI8_RESID>(g,5); if(c.epi==EPI8_GELU) t=run<EPI8_GELU>(g,5);
-    printf("%s : %.3f ms %.0f TF\n", c.name, t, 2.0*M*c.N*c.K/t/1e9);
+    g.N=c.N; g.K=c.K; g.n_groups = c.epi==EPI8_GELU ? 2 : 1; float t=0, t0=0;
+    if(c.epi==EPI8_QKV) t=run<EPI8_QKV>(g,5,&t0); if(c.epi==EPI8_RESID) t=run<EPI8_RESID>(g,5,&t0); if(c.epi==EPI8_GELU) t=run<EPI8_GELU>(g,5,&t0);
+    printf("%s : split %.3f ms %.0f TF | round-2 form %.3f ms %.0f TF\n", c.name, t, 2.0*M*c.N*c.K/t/1e9, t0, 2.0*M*c.N*c.K/t0/1e9);
+    {   // same bits from both forms (same MFMA order per output element)
+      const size_t nb = c.epi==EPI8_GELU ? (size_t)M*3072*2 : (size_t)M*768*2; bf16* out = c.epi==EPI8_GELU ? h : (c.epi==EPI8_RESID ? yb : k);
+      std::vector<unsigned short> a(nb/2), b(nb/2);
+      CK(hipMemset(out, 0xff, nb));
+      if(c.epi==EPI8_QKV) gemm8_kernel<EPI8_QKV,false><<<256,512,131072>>>(g); if(c.epi==EPI8_RESID) gemm8_kernel<EPI8_RESID,false><<<256,512,131072>>>(g); if(c.epi==EPI8_GELU) gemm8_kernel<EPI8_GELU,false><<<256,512,131072>>>(g);
+      CK(hipDeviceSynchronize()); CK(hipMemcpy(a.data(), out, nb, hipMemcpyDeviceToHost));
+      CK(hipMemset(out, 0xff, nb));
+      if(c.epi==EPI8_QKV) gemm8_kernel<EPI8_QKV,true><<<256,512,163840>>>(g); if(c.epi==EPI8_RESID) gemm8_kernel<EPI8_RESID,true><<<256,512,163840>>>(g); if(c.epi==EPI8_GELU) gemm8_kernel<EPI8_GELU,true><<<256,512,163840>>>(g);
+      CK(hipDeviceSynchronize()); CK(hipMemcpy(b.data(), out, nb, hipMemcpyDeviceToHost));
+      size_t diff = 0; for (size_t i = 0; i < a.size(); ++i) diff += a[i] != b[i];
+      printf("   outputs of the two forms differ in %zu of %zu elements\n", diff, a.size()); }
+#ifdef G8_STAMP2
+    for (int form = 0; form < 2; ++form) {
+      CK(hipMemset(part, 0, 2048));
+      if (form) { if(c.epi==EPI8_QKV) gemm8_kernel<EPI8_QKV,true><<<256,512,163840>>>(g); if(c.epi==EPI8_RESID) gemm8_kernel<EPI8_RESID,true><<<256,512,163840>>>(g); if(c.epi==EPI8_GELU) gemm8_kernel<EPI8_GELU,true><<<256,512,163840>>>(g); }
+      else { if(c.epi==EPI8_QKV) gemm8_kernel<EPI8_QKV,false><<<256,512,131072>>>(g); if(c.epi==EPI8_RESID) gemm8_kernel<EPI8_RESID,false><<<256,512,131072>>>(g); if(c.epi==EPI8_GELU) gemm8_kernel<EPI8_GELU,false><<<256,512,131072>>>(g); }
+      CK(hipDeviceSynchronize());
+      unsigned long long hs[96]; CK(hipMemcpy(hs, part, sizeof hs, hipMemcpyDeviceToHost));
+      for (int gq = 0; gq < 2; ++gq) { unsigned long long* h = hs + 64 + gq*16;
+        if (form) printf("   split   group %d: R1 pieces %llu reads %llu | R2 pieces %llu reads %llu\n", gq, h[12]-h[0], h[1]-h[12], h[13]-h[6], h[7]-h[13]);
+        printf("   %s group %d k-tile 6 of tile 3: R1 reads %llu | stage %llu | lgkm wait %llu | barrier %llu | M1 %llu | barrier %llu | R2 reads %llu | stage+waits %llu | barrier %llu | M2 %llu | barrier %llu | total %llu\n",
+          form ? "split  " : "round-2", gq, h[1]-h[0], h[2]-h[1], h[3]-h[2], h[4]-h[3], h[5]-h[4], h[6]-h[5], h[7]-h[6], h[8]-h[7], h[9]-h[8], h[10]-h[9], h[11]-h[10], h[11]-h[0]); } }
+#endif
 #ifdef G8_STAMP
     { unsigned long long hs[64]; CK(hipMemcpy(hs, part, sizeof hs, hipMemcpyDeviceToHost));
       for (int gq = 0; gq < 2; ++gq) { unsigned long long* h = hs + gq*16; if (h[10]) printf("   group %d RESID epilogue: loads issued %llu | band0 wait+compute %llu | band1 load+compute %llu | stores issued %llu\n", gq, h[10]-h[1], h[11]-h[10], h[12]-h[11], h[13]-h[12]); printf("   group %d: kloop-end->aligned %llu | +2 stages & drain %llu | epilogue issue %llu | ->k0 barrier %llu | k0->k1 %llu | k1->k2 %llu | k2->k3 %llu\n", gq,
