@@ -62,8 +62,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct SegDesc {
     const float4 *ptr;  // tiled rows of this segment (T64, fp32)
+    const uint4 *himg;  // the segment's fp16 image (H64, scan_split.inc); null until a search takes the prefilter path
     u32 gstart;         // first global group index of this segment
-    u32 hoff64;         // the segment's fp16 image (H64, scan_split.inc) starts hoff64 * 64 bytes behind ptr
+    u32 pad_;
 };
 
 // ------------------------------------------------------------------ key packing
@@ -88,6 +89,7 @@ __device__ __forceinline__ u64 make_key(float s, u32 pos) {
 // f4: plain 4-float vector (HIP's float4 class cannot be copied out of address_space(1)).
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) f4 *gf4ptr;
+typedef const float4 *gf4ptr_t;
 __device__ __forceinline__ gf4ptr as_global(const float4 *p) { return (gf4ptr)(p); }
 
 __device__ __forceinline__ void lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(256) void tile_rows_kernel(const float4 *__restrict
     const long gd = row0 / GROUP_ROWS + blockIdx.x;
     const long r_lo = max(row0, gd * GROUP_ROWS), r_hi = min(row0 + m, gd * GROUP_ROWS + GROUP_ROWS);
     float4 *dst = seg + gd * (long)K4 * GROUP_ROWS;
-    uint4 *hdst = hseg + gd * (long)K4 * (GROUP_ROWS / 2);   // 16-byte pieces: K4 * 512 bytes per group
+    uint4 *hdst = hseg ? hseg + gd * (long)K4 * (GROUP_ROWS / 2) : nullptr;   // 16-byte pieces: K4 * 512 bytes per group
     // |x|^2 of the rows passing through (thread = 4 rows x one of 16 column lanes): the largest row norm of
     // the index is the scale of the half-precision prefilter's error bound (scan_split.inc)
     float ss[4] = {0.f, 0.f, 0.f, 0.f};
@@ -177,8 +179,9 @@ __global__ __launch_bounds__(256) void tile_rows_kernel(const float4 *__restrict
             const long dr = gd * GROUP_ROWS + r;
             if (dr >= r_lo && dr < r_hi && k4b + c < K4) dst[(long)(k4b + c) * GROUP_ROWS + r] = tile[c][r];
         }
-        // fp16 image: the 16 chunks are 4 steps; piece pid = (step, hf, hh, r) holds chunks 4*step + 2*hh, +1 of row 32*hf + r
-        for (int pid = tid; pid < 512; pid += 256) {
+        // fp16 image (once the index has one): the 16 chunks are 4 steps; piece pid = (step, hf, hh, r) holds chunks
+        // 4*step + 2*hh, +1 of row 32*hf + r
+        for (int pid = tid; pid < 512 && hdst; pid += 256) {
             const int tl = pid >> 7, hf = (pid >> 6) & 1, hh = (pid >> 5) & 1, r = 32 * hf + (pid & 31), c0 = 4 * tl + 2 * hh;
             const long dr = gd * GROUP_ROWS + r;
             if (dr >= r_lo && dr < r_hi && k4b + c0 < K4) {
@@ -206,6 +209,25 @@ __global__ __launch_bounds__(256) void tile_rows_kernel(const float4 *__restrict
     if ((tid & 63) == 0 && best != 0u) atomicMax(norm2_max_bits, best);
 }
 
+// The fp16 image of groups [g0, g0 + gridDim.x) of a segment from its fp32 tiles: what tile_rows_kernel writes beside the
+// tiles once the image exists.  It is built lazily, by the first search that takes the prefilter path: an index that only
+// ever sees a few queries per call (the HBM-bound regime) or has split = "0" never pays the +50 % of HBM.
+__global__ __launch_bounds__(256) void half_image_kernel(const float4 *__restrict__ seg, uint4 *__restrict__ hseg, long g0, int K4) {
+    const long gd = g0 + blockIdx.x;
+    const gf4ptr_t src = reinterpret_cast<gf4ptr_t>(seg) + gd * (long)K4 * GROUP_ROWS;
+    uint4 *hdst = hseg + gd * (long)K4 * (GROUP_ROWS / 2);
+    const int n_pieces = (K4 >> 2) * 128;
+    for (int p = threadIdx.x; p < n_pieces; p += 256) {
+        const int st = p >> 7, hf = (p >> 6) & 1, hh = (p >> 5) & 1, r = 32 * hf + (p & 31), c0 = 4 * st + 2 * hh;
+        const float4 a = src[(long)c0 * GROUP_ROWS + r], b = src[(long)(c0 + 1) * GROUP_ROWS + r];
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        h8 h;
+        h[0] = (_Float16)a.x; h[1] = (_Float16)a.y; h[2] = (_Float16)a.z; h[3] = (_Float16)a.w;
+        h[4] = (_Float16)b.x; h[5] = (_Float16)b.y; h[6] = (_Float16)b.z; h[7] = (_Float16)b.w;
+        hdst[p] = __builtin_bit_cast(uint4, h);
+    }
+}
+
 // ------------------------------------------------------------------ scan kernel
 struct ScanArgs {
     const SegDesc *segs;
@@ -220,7 +242,32 @@ struct ScanArgs {
     u64 *partial;           // [nq][gridDim.x * k] survivors of all workgroups, densely appended per query
     u32 *partial_cnt;       // [nq] entries appended so far (zeroed before the launch)
     u32 pos_base;
+    // Searches whose query count is only known on the device (the prefilter's fallback, decided without a host read-back):
+    // nq is then the capacity the grid was sized for and *nq_dev the number of queries actually present (0 in the common
+    // case: every workgroup exits at once).  Workgroups of dead query tiles join the live ones (vgrid).
+    const int *nq_dev;
 };
+
+struct VGrid {
+    u32 bx, by, nx;   // row stream, query tile, row streams per query tile: what blockIdx.x, blockIdx.y, gridDim.x are without nq_dev
+    int nq;
+};
+__device__ __forceinline__ bool vgrid(const ScanArgs &a, int QT, VGrid &v) {
+    v.bx = blockIdx.x;
+    v.by = blockIdx.y;
+    v.nx = gridDim.x;
+    v.nq = a.nq;
+    if (!a.nq_dev) return true;
+    const int nq = min(a.nq, *a.nq_dev);
+    if (nq <= 0) return false;
+    const u32 T = (u32)(nq + QT - 1) / (u32)QT, W = gridDim.x * gridDim.y, w = blockIdx.y * gridDim.x + blockIdx.x, S = W / T;
+    if (w >= S * T) return false;
+    v.bx = w / T;
+    v.by = w % T;
+    v.nx = S;
+    v.nq = nq;
+    return true;
+}
 
 __device__ __forceinline__ gf4ptr group_ptr(const ScanArgs &a, u32 g) {
     int s = 0;
@@ -232,7 +279,7 @@ __device__ __forceinline__ gf4ptr group_ptr(const ScanArgs &a, u32 g) {
 // appended densely to the query's global list (one atomicAdd reserves the range), unsorted unless the
 // workgroup holds more than k: the merge kernel filters and sorts anyway, and reads only what was
 // appended instead of gridDim.x fixed k-slot lists that are mostly padding.
-__device__ __forceinline__ void flush_survivors(const ScanArgs &a, int q, u64 *b, u32 n, int lane) {
+__device__ __forceinline__ void flush_survivors(const ScanArgs &a, u32 n_streams, int q, u64 *b, u32 n, int lane) {
     if (n == 0) return;
     if (n > (u32)a.k) {
         wave_sort_desc(b, n, lane);
@@ -241,7 +288,7 @@ __device__ __forceinline__ void flush_survivors(const ScanArgs &a, int q, u64 *b
     u32 base = 0;
     if (lane == 0) base = atomicAdd(&a.partial_cnt[q], n);
     base = __shfl(base, 0);
-    u64 *out = a.partial + (size_t)q * gridDim.x * a.k + base;
+    u64 *out = a.partial + (size_t)q * n_streams * a.k + base;
     for (u32 i = lane; i < n; i += 64) out[i] = b[i];
 }
 
@@ -257,8 +304,10 @@ __global__ __launch_bounds__(SCAN_WAVES * 64) void scan16_kernel(ScanArgs a) {
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K4 = a.K4;
-    const int q0 = blockIdx.y * a.QT;
-    const int QTr = min(a.QT, a.nq - q0);
+    VGrid vg;
+    if (!vgrid(a, a.QT, vg)) return;
+    const int q0 = vg.by * a.QT;
+    const int QTr = min(a.QT, vg.nq - q0);
     const int C = a.C;
 
     f4 *ldsQ = reinterpret_cast<f4 *>(smem);                       // [K4][QTr]
@@ -279,11 +328,11 @@ __global__ __launch_bounds__(SCAN_WAVES * 64) void scan16_kernel(ScanArgs a) {
     const int j = lane & 15;
     const int jc = min(j, QTr - 1);
     const f4 *qb = ldsQ + jc;
-    const u32 stride = gridDim.x * SCAN_WAVES;
+    const u32 stride = vg.nx * SCAN_WAVES;
     const u32 nrounds = (a.n_items + stride - 1) / stride;
     const u32 hw = (u32)C - 64u * SCAN_WAVES;  // compaction high-water mark (>= k)
 
-    u32 item = blockIdx.x * SCAN_WAVES + w;
+    u32 item = vg.bx * SCAN_WAVES + w;
     bool have = item < a.n_items;
     gf4ptr gp = group_ptr(a, a.g_first + (have ? item : 0) * a.g_step) + lane;
     f4 ring[PF];
@@ -385,7 +434,7 @@ __global__ __launch_bounds__(SCAN_WAVES * 64) void scan16_kernel(ScanArgs a) {
     for (int jj = w; jj < QTr; jj += SCAN_WAVES) {
         const u32 n = cnt[jj];
         u64 *b = cand + (size_t)jj * C;
-        flush_survivors(a, q0 + jj, b, n, lane);
+        flush_survivors(a, vg.nx, q0 + jj, b, n, lane);
     }
 }
 
@@ -433,8 +482,10 @@ __global__ __launch_bounds__(W * 64) void scanq_kernel(ScanArgs a) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K4 = a.K4;
     const int NS = K4 / KC;
-    const int q0 = blockIdx.y * NQ;
-    const int NQr = min(NQ, a.nq - q0);
+    VGrid vg;
+    if (!vgrid(a, NQ, vg)) return;
+    const int q0 = vg.by * NQ;
+    const int NQr = min(NQ, vg.nq - q0);
     const int C = a.C;
 
     f4 *qs = reinterpret_cast<f4 *>(smem);                         // [2][KC][NQ]
@@ -442,7 +493,7 @@ __global__ __launch_bounds__(W * 64) void scanq_kernel(ScanArgs a) {
     u32 *cnt = reinterpret_cast<u32 *>(cand + (size_t)NQ * C);             // [NQ]
     float *thr = reinterpret_cast<float *>(cnt + NQ);                      // [NQ]
     u32 *ovf = reinterpret_cast<u32 *>(thr + NQ);                          // [1]
-    gf4ptr qsrc = as_global(a.qt) + (size_t)blockIdx.y * K4 * NQ;
+    gf4ptr qsrc = as_global(a.qt) + (size_t)vg.by * K4 * NQ;
 
     for (int i = tid; i < NQ; i += NTHR) {
         cnt[i] = 0;
@@ -454,11 +505,11 @@ __global__ __launch_bounds__(W * 64) void scanq_kernel(ScanArgs a) {
     __syncthreads();
 
     const int jl = lane & 31;
-    const u32 stride = gridDim.x * W;
+    const u32 stride = vg.nx * W;
     const u32 nrounds = (a.n_items + stride - 1) / stride;
     const u32 hw = (u32)(C + a.k) / 2;  // compact once a buffer is past the midpoint of its slack
 
-    u32 item = blockIdx.x * W + w;
+    u32 item = vg.bx * W + w;
     bool have = item < a.n_items;
     gf4ptr gp = group_ptr(a, a.g_first + (have ? item : 0) * a.g_step) + lane;
     f4 ring[PF];
@@ -623,7 +674,7 @@ __global__ __launch_bounds__(W * 64) void scanq_kernel(ScanArgs a) {
     for (int jj = w; jj < NQr; jj += W) {
         u32 n = cnt[jj];
         if (n > (u32)C) n = (u32)C;
-        flush_survivors(a, q0 + jj, cand + (size_t)jj * C, n, lane);
+        flush_survivors(a, vg.nx, q0 + jj, cand + (size_t)jj * C, n, lane);
     }
 }
 
@@ -853,10 +904,11 @@ u32 next_pow2(u32 v) {
 
 // ------------------------------------------------------------------ one-device index
 struct Segment {
-    float4 *buf = nullptr;   // one allocation: cap_rows * d fp32 (T64 tiles), then cap_rows * d fp16 (H64 image)
+    float4 *buf = nullptr;   // cap_rows * d fp32 (T64 tiles)
+    uint4 *hbuf = nullptr;   // cap_rows * d fp16 (H64 image): allocated by the first search that takes the prefilter path
     int64_t cap_rows = 0;    // multiple of 64
     int64_t rows = 0;
-    uint4 *himg(int d) const { return reinterpret_cast<uint4 *>(reinterpret_cast<char *>(buf) + (size_t)cap_rows * d * 4); }
+    int64_t h_rows = 0;      // rows whose fp16 image is current (tile_rows_kernel keeps it current once hbuf exists)
 };
 
 struct DeviceIndex {
@@ -878,6 +930,7 @@ struct DeviceIndex {
         int scanq_waves = 8;
         bool no_p8 = false;
         int seed_groups_max = 0;         // cap of the seeding pass of the prefilter scan, in 64-row groups; 0 = 14 sqrt(groups)
+        int split_decide = -1;           // who reads the certificates: -1 by entry point (host API: host, *_device: device), 0 host, 1 device
     } tune;
     void read_env() {
         if (const char *e = getenv("HAC_SPLIT")) tune.split = e[0] == '0' ? 0 : (e[0] == '1' ? 1 : -1);
@@ -917,6 +970,9 @@ struct DeviceIndex {
         } else if (n == "scan_no_p8") {
             if (!one_of({"0", "1"})) return HAC_ERR_INVALID;
             tune.no_p8 = v == "1";
+        } else if (n == "split_decide") {
+            if (!one_of({"auto", "host", "device"})) return HAC_ERR_INVALID;
+            tune.split_decide = v == "host" ? 0 : (v == "device" ? 1 : -1);
         } else if (n == "seed_groups_max") {
             char *end = nullptr;
             const long t = strtol(v.c_str(), &end, 10);
@@ -998,8 +1054,10 @@ struct DeviceIndex {
     void destroy() {
         DeviceGuard g(device);
         if (stream) (void)hipStreamSynchronize(stream);
-        for (auto &s : segs)
+        for (auto &s : segs) {
             if (s.buf) (void)hipFree(s.buf);
+            if (s.hbuf) (void)hipFree(s.hbuf);
+        }
         segs.clear();
         if (d_segs) (void)hipFree(d_segs);
         if (h_segs) (void)hipHostFree(h_segs);
@@ -1039,9 +1097,11 @@ struct DeviceIndex {
             if (i == best) {
                 Segment s = segs[i];
                 s.rows = 0;
+                s.h_rows = 0;
                 keep.push_back(s);
             } else if (segs[i].buf) {
                 HAC_HIP(hipFree(segs[i].buf));
+                if (segs[i].hbuf) HAC_HIP(hipFree(segs[i].hbuf));
             }
         }
         segs.swap(keep);
@@ -1059,13 +1119,37 @@ struct DeviceIndex {
         s.cap_rows = (rows_needed + GROUP_ROWS - 1) / GROUP_ROWS * GROUP_ROWS;
         const size_t bytes = (size_t)s.cap_rows * d * sizeof(float);
         if ((bytes >> 6) > 0xFFFFFFFFull) return fail(HAC_ERR_UNSUPPORTED, "a single add() of %lld rows exceeds the segment size limit (256 GiB of fp32 rows)", (long long)rows_needed);
-        hipError_t e = hipMalloc((void **)&s.buf, bytes + bytes / 2);   // fp32 tiles + fp16 image
-        if (e != hipSuccess) return fail(HAC_ERR_OOM, "hipMalloc(%zu) for %lld rows failed: %s", bytes + bytes / 2, (long long)rows_needed, hipGetErrorString(e));
-        // zero the last group of both images so that padding rows are finite
+        hipError_t e = hipMalloc((void **)&s.buf, bytes);   // the fp32 tiles; the fp16 image comes with the first prefilter search
+        if (e != hipSuccess) return fail(HAC_ERR_OOM, "hipMalloc(%zu) for %lld rows failed: %s", bytes, (long long)rows_needed, hipGetErrorString(e));
+        // zero the last group so that padding rows are finite
         const size_t gbytes = (size_t)GROUP_ROWS * d * sizeof(float);
         HAC_HIP(hipMemsetAsync((char *)s.buf + bytes - gbytes, 0, gbytes, st));
-        HAC_HIP(hipMemsetAsync((char *)s.buf + bytes + bytes / 2 - gbytes / 2, 0, gbytes / 2, st));
         segs.push_back(s);
+        return HAC_OK;
+    }
+
+    // The fp16 image of every segment, current up to its last row: allocated and filled the first time a search takes the
+    // prefilter path (+50 % of the corpus bytes, which an index that only ever scans with a few queries, or runs with
+    // split = "0", never spends), extended here for rows added since to a segment that had none.  Segments that own an image
+    // get their new rows' pieces from tile_rows_kernel directly.
+    int ensure_half_image(hipStream_t st) {
+        for (auto &s : segs) {
+            if (s.rows == 0 || (s.hbuf && s.h_rows == s.rows)) continue;
+            if (!s.hbuf) {
+                const size_t hbytes = (size_t)s.cap_rows * d * 2;
+                hipError_t e = hipMalloc((void **)&s.hbuf, hbytes);
+                if (e != hipSuccess) return fail(HAC_ERR_OOM, "hipMalloc(%zu) for the fp16 image of %lld rows failed: %s (split = \"0\" searches without it)", hbytes,
+                                                 (long long)s.cap_rows, hipGetErrorString(e));
+                s.h_rows = 0;
+                segs_dirty = true;
+            }
+            const long g_lo = (long)(s.h_rows / GROUP_ROWS), g_hi = (long)((s.rows + GROUP_ROWS - 1) / GROUP_ROWS);
+            if (g_hi > g_lo) {
+                half_image_kernel<<<dim3((unsigned)(g_hi - g_lo)), dim3(256), 0, st>>>(s.buf, s.hbuf, g_lo, K4);
+                HAC_HIP(hipGetLastError());
+            }
+            s.h_rows = s.rows;
+        }
         return HAC_OK;
     }
 
@@ -1075,19 +1159,20 @@ struct DeviceIndex {
         for (auto &s : segs) total_cap += (s.rows + GROUP_ROWS - 1) / GROUP_ROWS * GROUP_ROWS;
         Segment big;
         big.cap_rows = total_cap;
-        HAC_HIP(hipMalloc((void **)&big.buf, (size_t)total_cap * d * 6));
+        HAC_HIP(hipMalloc((void **)&big.buf, (size_t)total_cap * d * 4));
         int64_t off_rows = 0;
         for (auto &s : segs) {
             const int64_t gr = (s.rows + GROUP_ROWS - 1) / GROUP_ROWS * GROUP_ROWS;
-            if (gr) {
-                HAC_HIP(hipMemcpyAsync((char *)big.buf + (size_t)off_rows * d * 4, s.buf, (size_t)gr * d * 4, hipMemcpyDeviceToDevice, st));
-                HAC_HIP(hipMemcpyAsync((char *)big.himg(d) + (size_t)off_rows * d * 2, s.himg(d), (size_t)gr * d * 2, hipMemcpyDeviceToDevice, st));
-            }
+            if (gr) HAC_HIP(hipMemcpyAsync((char *)big.buf + (size_t)off_rows * d * 4, s.buf, (size_t)gr * d * 4, hipMemcpyDeviceToDevice, st));
             off_rows += gr;
             big.rows += s.rows;
         }
         HAC_HIP(hipStreamSynchronize(st));
-        for (auto &s : segs) HAC_HIP(hipFree(s.buf));
+        // the fused segment's fp16 image is rebuilt from its tiles by the next prefilter search (ensure_half_image)
+        for (auto &s : segs) {
+            HAC_HIP(hipFree(s.buf));
+            if (s.hbuf) HAC_HIP(hipFree(s.hbuf));
+        }
         segs.clear();
         segs.push_back(big);
         segs_dirty = true;
@@ -1110,8 +1195,10 @@ struct DeviceIndex {
             const long row0 = (long)s.rows;
             const long g_lo = row0 / GROUP_ROWS, g_hi = (row0 + m + GROUP_ROWS - 1) / GROUP_ROWS;
             tile_rows_kernel<<<dim3((unsigned)(g_hi - g_lo)), dim3(256), 0, st>>>(
-                reinterpret_cast<const float4 *>(src_dev + (size_t)done * d), (long)m, K4, s.buf, s.himg(d), row0, (u32 *)ws_norm.p);
+                reinterpret_cast<const float4 *>(src_dev + (size_t)done * d), (long)m, K4, s.buf, s.hbuf && s.h_rows == s.rows ? s.hbuf : nullptr, row0,
+                (u32 *)ws_norm.p);
             HAC_HIP(hipGetLastError());
+            if (s.hbuf && s.h_rows == s.rows) s.h_rows += m;
             s.rows += m;
             done += m;
         }
@@ -1176,8 +1263,9 @@ struct DeviceIndex {
         for (auto &s : segs) {
             if (s.rows == 0) continue;
             h[n].ptr = s.buf;
+            h[n].himg = s.hbuf;
             h[n].gstart = g;
-            h[n].hoff64 = (u32)(((size_t)s.cap_rows * d * 4) >> 6);
+            h[n].pad_ = 0;
             g += (u32)((s.rows + GROUP_ROWS - 1) / GROUP_ROWS);
             ++n;
         }
@@ -1188,6 +1276,25 @@ struct DeviceIndex {
     }
     int nseg_live = 0;
     char last_plan[320] = "none";
+    // a device-decided prefilter search leaves its fallback count and err / bound on the device: plan() completes the text
+    char plan_head[200] = "";
+    bool plan_pending = false;
+    hipStream_t plan_stream = nullptr;
+    int64_t plan_nq = 0;
+    const char *plan() {
+        if (plan_pending) {
+            DeviceGuard g(device);
+            u32 st2[2] = {0, 0};
+            if (hipStreamSynchronize(plan_stream) == hipSuccess && hipMemcpy(st2, ws_stat.p, 8, hipMemcpyDeviceToHost) == hipSuccess) {
+                float maxratio;
+                std::memcpy(&maxratio, &st2[1], 4);
+                snprintf(last_plan, sizeof last_plan, "%s fallback=%u/%lld err/bound=%.3g decided=device", plan_head, st2[0], (long long)plan_nq, (double)maxratio);
+                split_fallback_queries += st2[0];
+            }
+            plan_pending = false;
+        }
+        return last_plan;
+    }
 
     struct Plan {
         int kind;  // 0: scan16 (<=16 queries per workgroup, Q resident in LDS)   1: scanq<NT,W>
@@ -1255,8 +1362,9 @@ struct DeviceIndex {
     }
 
     int run_scan(const Plan &pl, const float *q_dev, int64_t nq, int k, u32 g_first, u32 g_step, u32 n_items,
-                 const float *thr_init, u32 pos_base, int P, hipStream_t st, bool timed) {
+                 const float *thr_init, u32 pos_base, int P, hipStream_t st, bool timed, const int *nq_dev = nullptr) {
         ScanArgs a;
+        a.nq_dev = nq_dev;
         a.segs = d_segs;
         a.nseg = nseg_live;
         a.q = reinterpret_cast<const float4 *>(q_dev);
@@ -1310,8 +1418,11 @@ struct DeviceIndex {
         return HAC_OK;
     }
 
-    // keys_out: device u64 [nq][k]; the exact fp32 kernels only
-    int search_keys_exact(const float *q_dev, int64_t nq, int k, u64 *keys_out, u32 pos_base, hipStream_t st) {
+    // keys_out: device u64 [nq][k]; the exact fp32 kernels only.  nq_dev (optional): the number of queries present lives on
+    // the device and nq is the capacity everything is sized for (the prefilter's device-decided fallback): no threshold
+    // seeding (fewer launches on a path that is empty in the common case), the scan's workgroups are shared among the live
+    // query tiles (vgrid), and rows of keys_out beyond *nq_dev are left alone.
+    int search_keys_exact(const float *q_dev, int64_t nq, int k, u64 *keys_out, u32 pos_base, hipStream_t st, const int *nq_dev = nullptr) {
         if (nq == 0) return HAC_OK;
         if (((uintptr_t)q_dev & 15) != 0) return fail(HAC_ERR_INVALID, "search: query pointer must be 16-byte aligned");
         if ((uint64_t)pos_base + (uint64_t)ntotal > 0xFFFFFFFFull) return fail(HAC_ERR_UNSUPPORTED, "row positions exceed 32 bits");
@@ -1323,7 +1434,8 @@ struct DeviceIndex {
         const u32 G = (u32)((ntotal + GROUP_ROWS - 1) / GROUP_ROWS);
         Plan pl;
         HAC_TRY(make_plan(nq, k, G, pl));
-        HAC_TRY(ws_partial.reserve((size_t)nq * pl.P * k * 8));
+        // device-side count: a live tile may own every workgroup of the grid; QT * (P * n_qtiles) * k keys bound any split
+        HAC_TRY(ws_partial.reserve(nq_dev ? (size_t)pl.QT * pl.P * pl.n_qtiles * k * 8 : (size_t)nq * pl.P * k * 8));
         HAC_TRY(ws_pcnt.reserve((size_t)nq * 4));
         HAC_TRY(ws_thrglob.reserve((size_t)pl.n_qtiles * pl.QT * 4));
         if (pl.kind == 1) {
@@ -1338,7 +1450,7 @@ struct DeviceIndex {
         // lower bound of every query's final k-th score; it only filters, never decides.
         // sample ~1.6 % of the groups, at least 64 and enough for 2k maxima (4 per group)
         const u32 n_sample = std::max<u32>(std::max<u32>(64u, G / 64u), ((u32)k + 1u) / 2u);
-        if (G >= 4u * n_sample) {
+        if (G >= 4u * n_sample && !nq_dev) {
             const u32 S = 4u * n_sample;                             // four maxima per sample group
             HAC_TRY(ws_seedkeys.reserve((size_t)nq * S * 4));        // group maxima [nq][S]
             HAC_TRY(ws_thr.reserve((size_t)nq * 4));
@@ -1360,18 +1472,22 @@ struct DeviceIndex {
             HAC_HIP(hipGetLastError());
             thr_init = (const float *)ws_thr.p;
         }
-        if (pl.kind == 1)
+        if (nq_dev) {
+            // (the caller's plan stays: this is its fallback)
+        } else if (pl.kind == 1)
             snprintf(last_plan, sizeof last_plan, "scanq_kernel<NT=%d,W=%d> grid=(%d,%d) NQ=%d C=%d lds=%zu seed=%d", pl.NT, pl.W, pl.P,
                      pl.n_qtiles, pl.QT, pl.C, pl.lds_scan, thr_init ? 1 : 0);
         else
             snprintf(last_plan, sizeof last_plan, "scan16_kernel<W=%d> grid=(%d,%d) QT=%d C=%d lds=%zu seed=%d", SCAN_WAVES, pl.P,
                      pl.n_qtiles, pl.QT, pl.C, pl.lds_scan, thr_init ? 1 : 0);
-        HAC_TRY(run_scan(pl, q_dev, nq, k, 0, 1, G, thr_init, pos_base, pl.P, st, profiling));
+        if (!nq_dev) plan_pending = false;
+        HAC_TRY(run_scan(pl, q_dev, nq, k, 0, 1, G, thr_init, pos_base, pl.P, st, profiling, nq_dev));
         // the workgroups' survivors sit densely per query: radix select of the k best, one sort of k keys
         const int np2 = (int)next_pow2((u32)k);
         select_keys_kernel<<<dim3((unsigned)nq), dim3(256), (size_t)np2 * 8, st>>>((const u64 *)ws_partial.p, (size_t)pl.P * k,
                                                                                    (const u32 *)ws_pcnt.p, (u32)((size_t)pl.P * k), k, np2,
-                                                                                   keys_out, nullptr);
+                                                                                   keys_out, nullptr, nq_dev, (int)nq, (u32)(pl.P * pl.n_qtiles),
+                                                                                   (u32)pl.QT);
         HAC_HIP(hipGetLastError());
         return HAC_OK;
     }
@@ -1406,9 +1522,11 @@ struct DeviceIndex {
     // Queries go through in chunks of at most 1024 (four 256-query tiles x 64 row streams fill the chip): the
     // rescoring of chunk c (HBM gathers, no matrix work) runs on a second stream under the scan of chunk c+1.
     static constexpr int64_t SPLIT_CHUNK = 1024;
-    int search_keys_split(const float *q_dev, int64_t nq, int k, u64 *keys_out, u32 pos_base, hipStream_t st, int level = 0) {
+    int search_keys_split(const float *q_dev, int64_t nq, int k, u64 *keys_out, u32 pos_base, hipStream_t st, int level = 0,
+                          bool device_decides = false) {
         const int K2 = SPLIT_K2, C2 = SPLIT_C2;
         const int terms = level == 0 ? tune.split_terms : 3;   // split_terms = 3: tests pin the first level
+        HAC_TRY(ensure_half_image(st));
         HAC_TRY(upload_segs(st));
         const u32 G = (u32)((ntotal + GROUP_ROWS - 1) / GROUP_ROWS);
         const int64_t chunk = std::min<int64_t>(nq, SPLIT_CHUNK);
@@ -1527,6 +1645,44 @@ struct DeviceIndex {
         }
         HAC_HIP(hipEventRecord(ev_tail, stream2));
         HAC_HIP(hipStreamWaitEvent(st, ev_tail, 0));
+        if (device_decides) {
+            // No read-back: the failed queries (none, in the common case) are compacted into a list, searched again by the
+            // exact fp32 kernels and scattered back into place, every launch sized for all nq and cut down on the device by
+            // the count the certificates left in ws_stat[0].  The stream is never synchronized; the plan text (fallback
+            // count, err / bound) is completed when hac_index_last_plan asks for it.
+            GrowBuf &fbidx = ws_fbidx[0], &fbq = ws_fbq[0], &fbkeys = ws_fbkeys[0];
+            const int n_fchunks = (int)((nq + QUERY_CHUNK - 1) / QUERY_CHUNK);
+            HAC_TRY(fbidx.reserve(((size_t)nq + n_fchunks) * 4));
+            HAC_TRY(fbq.reserve((size_t)nq * d * 4));
+            HAC_TRY(fbkeys.reserve((size_t)nq * k * 8));
+            int *chunk_cnt = (int *)fbidx.p + nq;
+            compact_failed_kernel<<<dim3(1), dim3(256), 0, st>>>((const u32 *)ws_fail.p, (int)nq, (int *)fbidx.p, chunk_cnt, n_fchunks, (int)QUERY_CHUNK);
+            HAC_HIP(hipGetLastError());
+            const int *nf_dev = (const int *)ws_stat.p;
+            gather_rows_kernel<<<dim3((unsigned)(((long)nq * K4 + 255) / 256)), dim3(256), 0, st>>>(
+                reinterpret_cast<const float4 *>(q_dev), (const int *)fbidx.p, (int)nq, K4, (float4 *)fbq.p, nf_dev);
+            HAC_HIP(hipGetLastError());
+            const bool prof = profiling;
+            profiling = false;   // timed kernels of a search: the prefilter's scans
+            int rc = HAC_OK;
+            for (int c = 0; c < n_fchunks && rc == HAC_OK; ++c) {
+                const int64_t off = (int64_t)c * QUERY_CHUNK, n = std::min<int64_t>(QUERY_CHUNK, nq - off);
+                rc = search_keys_exact((const float *)fbq.p + (size_t)off * d, n, k, (u64 *)fbkeys.p + (size_t)off * k, pos_base, st, chunk_cnt + c);
+            }
+            profiling = prof;
+            HAC_TRY(rc);
+            scatter_keys_kernel<<<dim3((unsigned)(((long)nq * k + 255) / 256)), dim3(256), 0, st>>>((const u64 *)fbkeys.p, (const int *)fbidx.p,
+                                                                                                  (int)nq, k, keys_out, nf_dev);
+            HAC_HIP(hipGetLastError());
+            ++split_searches;
+            snprintf(plan_head, sizeof plan_head, "split: scanh_kernel<%d> grid=(%ld,%d) NQ=%d K2=%d chunks=%d lds=%zu seed=%d", terms, P_last,
+                     n_qtiles_last, SH_NQ, K2, n_chunks, lds, seeded);
+            snprintf(last_plan, sizeof last_plan, "%s fallback=device-side/%lld", plan_head, (long long)nq);
+            plan_pending = true;
+            plan_stream = st;
+            plan_nq = nq;
+            return HAC_OK;
+        }
         HAC_HIP(hipMemcpyAsync(h_fb, ws_stat.p, 8, hipMemcpyDeviceToHost, st));
         HAC_HIP(hipStreamSynchronize(st));
         const u32 nfail = h_fb[0];
@@ -1537,6 +1693,7 @@ struct DeviceIndex {
         snprintf(plan_here, sizeof plan_here, "split: scanh_kernel<%d> grid=(%ld,%d) NQ=%d K2=%d chunks=%d lds=%zu seed=%d fallback=%u/%lld err/bound=%.3g",
                  terms, P_last, n_qtiles_last, SH_NQ, K2, n_chunks, lds, seeded, nfail, (long long)nq, (double)maxratio);
         std::memcpy(last_plan, plan_here, sizeof last_plan);
+        plan_pending = false;
         if (nfail == 0) return HAC_OK;
 
         // certificate failed for some queries: the next level decides those
@@ -1584,12 +1741,15 @@ struct DeviceIndex {
     // in chunks: 512 inside the prefilter (search_keys_split), 1024 for the exact kernels (16 query tiles x 16
     // row streams fill the chip with same-row workgroups sharing an XCD; one launch over 33 query tiles does neither).
     static constexpr int64_t QUERY_CHUNK = 1024;
-    int search_keys(const float *q_dev, int64_t nq, int k, u64 *keys_out, u32 pos_base, hipStream_t st) {
+    // device_entry: the call came through a *_device entry point, which must not synchronize the caller's stream: the
+    // prefilter's certificates are then read by the device (option split_decide pins either way for tests)
+    int search_keys(const float *q_dev, int64_t nq, int k, u64 *keys_out, u32 pos_base, hipStream_t st, bool device_entry = false) {
         if (nq > 0 && ntotal > 0) {
             if (((uintptr_t)q_dev & 15) != 0) return fail(HAC_ERR_INVALID, "search: query pointer must be 16-byte aligned");
             if ((uint64_t)pos_base + (uint64_t)ntotal > 0xFFFFFFFFull) return fail(HAC_ERR_UNSUPPORTED, "row positions exceed 32 bits");
         }
-        if (nq > 0 && ntotal > 0 && split_eligible(nq, k)) return search_keys_split(q_dev, nq, k, keys_out, pos_base, st);
+        if (nq > 0 && ntotal > 0 && split_eligible(nq, k))
+            return search_keys_split(q_dev, nq, k, keys_out, pos_base, st, 0, tune.split_decide < 0 ? device_entry : tune.split_decide == 1);
         for (int64_t off = 0; off < nq || off == 0; off += QUERY_CHUNK) {
             const int64_t n = std::min<int64_t>(QUERY_CHUNK, nq - off);
             HAC_TRY(search_keys_exact(q_dev + (size_t)off * d, n, k, keys_out + (size_t)off * k, pos_base, st));
@@ -1741,7 +1901,7 @@ int hac_index_search_keys_device(hac_index *idx, const float *q_dev, int64_t nq,
     if (nq < 0 || (nq > 0 && (!q_dev || !keys_dev))) return fail(HAC_ERR_INVALID, "search: bad arguments");
     DeviceIndex *s = idx->shards[0];
     DeviceGuard g(s->device);
-    return s->search_keys(q_dev, nq, k, (u64 *)keys_dev, pos_base, (hipStream_t)hip_stream);
+    return s->search_keys(q_dev, nq, k, (u64 *)keys_dev, pos_base, (hipStream_t)hip_stream, true);
 }
 
 int hac_keys_to_results_device(int device, const uint64_t *keys_dev, int64_t n_keys, const int64_t *id_map_dev,
@@ -1787,7 +1947,7 @@ int hac_index_search_device(hac_index *idx, const float *q_dev, int64_t nq, int 
     DeviceIndex *s = idx->shards[0];
     DeviceGuard g(s->device);
     HAC_TRY(s->ws_keys.reserve((size_t)nq * k * 8));
-    HAC_TRY(s->search_keys(q_dev, nq, k, (u64 *)s->ws_keys.p, 0u, (hipStream_t)hip_stream));
+    HAC_TRY(s->search_keys(q_dev, nq, k, (u64 *)s->ws_keys.p, 0u, (hipStream_t)hip_stream, true));
     return hac_keys_to_results_device(s->device, (const uint64_t *)s->ws_keys.p, nq * k, id_map_dev, D_dev, I_dev, hip_stream);
 }
 
@@ -1892,7 +2052,7 @@ int hac_index_set_profiling(hac_index *idx, int enable) {
 }
 
 const char *hac_index_last_plan(const hac_index *idx) {
-    return (idx && !idx->shards.empty()) ? idx->shards[0]->last_plan : "none";
+    return (idx && !idx->shards.empty()) ? idx->shards[0]->plan() : "none";
 }
 
 int hac_index_profile_drain(hac_index *idx, float *ms_out, int cap, int *n_out) {

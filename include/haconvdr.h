@@ -88,9 +88,16 @@ int hac_index_add_device(hac_index *idx, const float *x_dev, int64_t n, void *hi
  * candidates are rescored exactly and each query's list is certified complete; queries
  * that cannot be certified are searched again by the exact fp32 kernels.
  * The results are the same bits either way.  hac_index_set_option(idx, "split", "0") disables
- * the screen, "1" applies it whenever the shape allows (tests), "auto" decides by size.  That
- * path reads a small status word back, so the *_device variants synchronize the stream they
- * are given. */
+ * the screen, "1" applies it whenever the shape allows (tests), "auto" decides by size.
+ * The host entry point reads the certificates back (and may retry many failures with three
+ * fp16 products per score before the exact kernels); the *_device entry points leave the
+ * decision on the device -- failed queries are compacted, searched again by the exact kernels
+ * and scattered back by launches sized for every query and cut down by a device-side count --
+ * and never synchronize or read back: they can be captured into a HIP graph once workspaces,
+ * the segment table (re-uploaded by the first search after an add / reset, which does
+ * synchronize once) and the fp16 image exist.  That image (+50 % of the corpus bytes in HBM)
+ * is built by the first search that takes the screen; an index that never does (few queries
+ * per call, or split = "0") never allocates it. */
 int hac_index_search(hac_index *idx, const float *q, int64_t nq, int k, float *D, int64_t *I);
 /* Device/stream variant (single-device index).  id_map_dev (optional, int64
  * [ntotal]) maps row -> external id, fusing `passage_embedding2id[I]` (:110). */
@@ -109,7 +116,8 @@ int64_t hac_index_ntotal(const hac_index *idx);
 
 /* Tuning and test switches of a live handle: "split" = "0" | "1" | "auto", "split_terms" = "1" | "3",
  * "force_scan16" = "0" | "1", "scanq_nt" = "0".."4", "scanq_waves" = "4" | "8", "scan_no_p8" = "0" | "1",
- * "seed_groups_max" = cap of the prefilter's seeding pass in 64-row groups (integer >= 0; 0 = 14 sqrt(groups)).
+ * "seed_groups_max" = cap of the prefilter's seeding pass in 64-row groups (integer >= 0; 0 = 14 sqrt(groups)),
+ * "split_decide" = "auto" (host entry point: host, *_device: device) | "host" | "device": who reads the certificates.
  * Any other name or value is HAC_ERR_INVALID (never a silent default).
  * The HAC_<NAME> environment variables give the defaults and are read once, in hac_index_create. */
 int hac_index_set_option(hac_index *idx, const char *name, const char *value);

@@ -810,3 +810,138 @@ def test_split_prefilter_randomized_differential(monkeypatch):
         np.testing.assert_array_equal(I1, I0, err_msg=f"case {case} {kind} d={d} n={n} nq={nq} k={k}: {plan}")
         np.testing.assert_array_equal(D1, D0, err_msg=f"case {case} {kind} d={d} n={n} nq={nq} k={k}: {plan}")
         del idx
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Device-decided prefilter (the *_device entry points never synchronize the caller's stream) and the lazy fp16 image.
+def test_device_search_is_graph_capturable_on_the_prefilter_path(oracle):
+    """hac_index_search_device on the prefilter path enqueues and returns: no hipStreamSynchronize, no read-back -- checked
+    the hard way, by capturing a search into a HIP graph (a synchronize or a blocking copy inside a capture is an error)
+    and replaying it: the replay's results are the oracle's.  Certificates are read on the device; the fallback launches
+    are sized for every query and cut down by the device-side count (zero here)."""
+    import torch
+    from haconvdr_amd.index import FlatIPIndex
+    x, q, _ = cases.search_case_inputs("gauss", 0xCA97, 30000, 130)
+    idx = FlatIPIndex(768)
+    idx.set_option("split", "1")
+    idx.add(x)
+    qt = torch.from_numpy(q).cuda()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        D0, I0 = idx.search_tensor(qt, 100)            # warm-up: workspaces, fp16 image, segment table
+        side.synchronize()
+        assert idx.last_plan().startswith("split:") and "decided=device" in idx.last_plan(), idx.last_plan()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            D1, I1 = idx.search_tensor(qt, 100)
+        D1.zero_()
+        I1.zero_()
+        g.replay()
+        side.synchronize()
+    torch.cuda.synchronize()
+    oD, oI = oracle.flat_ip_search(x, q, 100)
+    assert_same(D1.cpu().numpy(), I1.cpu().numpy(), oD, oI)
+    assert_same(D0.cpu().numpy(), I0.cpu().numpy(), oD, oI)
+    nfail, nq_, ratio = _plan_fields(idx)
+    assert nq_ == len(q) and nfail == 0 and ratio < 0.25, idx.last_plan()
+
+
+@pytest.mark.parametrize("decide", ["host", "device"])
+def test_split_prefilter_fallback_paths_agree(decide, oracle):
+    """Queries the certificate cannot vouch for, decided by the host (read-back, cascade) and by the device (compaction +
+    count-guarded exact kernels whose workgroups are shared among the live query tiles): every query falls back (ties
+    wider than the candidate lists), a few do (a zero query, duplicated rows at the k-th score), none does.  Both the host
+    and the device entry point, same answers as the oracle."""
+    import torch
+    from haconvdr_amd.index import FlatIPIndex
+    x, q, _ = cases.search_case_inputs("gauss", 4243, 9000, 150)
+    idx = FlatIPIndex(768)
+    idx.set_option("split", "1")
+    idx.set_option("split_decide", decide)
+
+    def both(xx, qq, k):
+        D, I = idx.search(qq, k)
+        plan_h = idx.last_plan()
+        Dt, It = idx.search_tensor(torch.from_numpy(qq).cuda(), k)
+        torch.cuda.synchronize()
+        assert plan_h.startswith("split:") and idx.last_plan().startswith("split:")
+        assert ("decided=device" in idx.last_plan()) == (decide == "device"), idx.last_plan()
+        oD, oI = oracle.flat_ip_search(xx, qq, k)
+        assert_same(D, I, oD, oI)
+        assert_same(Dt.cpu().numpy(), It.cpu().numpy(), oD, oI)
+        return _plan_fields(idx)[0]
+    xd = np.tile(x[:10], (700, 1))                                # (a) everything ties: all 150 fall back
+    idx.add(xd)
+    assert both(xd, q, 100) == len(q)
+    idx.reset()
+    idx.add(x)                                                    # (b) a zero query and a NaN-free corpus: one or a few
+    qz = q.copy()
+    qz[3] = 0.0
+    qz[77] = 0.0
+    nf = both(x, qz, 100)
+    assert 2 <= nf <= 8
+    assert both(x, q, 10) == 0                                    # (c) nothing falls back
+    xn = x.copy()                                                 # (d) NaN / Inf rows: no bound, everything falls back
+    xn[17, 5] = np.nan
+    xn[4000, 700] = np.inf
+    idx.reset()
+    idx.add(xn)
+    assert both(xn, q[:70], 50) == 70
+
+
+def test_device_decided_fallback_with_more_queries_than_a_chunk(oracle):
+    """2100 queries (three chunks of the exact kernels' 1024) of which 1300 fall back: the per-chunk device counts."""
+    import torch
+    from haconvdr_amd.index import FlatIPIndex
+    x, q, _ = cases.search_case_inputs("gauss", 515, 5000, 2100)
+    q[::3] = 0.0                                                  # 700 zero queries: all scores tie
+    q[1::3] *= 1e-30                                              # and 700 whose products underflow in fp16: delta cannot certify
+    idx = FlatIPIndex(768)
+    idx.set_option("split", "1")
+    idx.add(x)
+    Dt, It = idx.search_tensor(torch.from_numpy(q).cuda(), 20)
+    torch.cuda.synchronize()
+    nfail, nq_, _ = _plan_fields(idx)
+    assert nq_ == 2100 and nfail >= 700, idx.last_plan()
+    sel = np.r_[0:40, 1000:1040, 2060:2100]
+    assert_same(Dt.cpu().numpy()[sel], It.cpu().numpy()[sel], *oracle.flat_ip_search(x, q[sel], 20))
+    idx.set_option("split", "0")
+    D0, I0 = idx.search(q, 20)
+    assert_same(Dt.cpu().numpy(), It.cpu().numpy(), D0, I0)
+
+
+def test_half_precision_image_is_built_lazily(oracle):
+    """The fp16 image (+50 % of the corpus bytes) exists only once a search takes the prefilter path: an index that scans
+    with a few queries per call, or with split = "0", never allocates it.  Rows added afterwards -- into the
+    partial tail group, into a new segment -- are searched correctly by the prefilter."""
+    import torch
+    from haconvdr_amd.index import FlatIPIndex
+    x, q, _ = cases.search_case_inputs("gauss", 0x1A2, 300000, 96)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free0 = torch.cuda.mem_get_info()[0]
+    idx = FlatIPIndex(768)
+    idx.add(x[:200000])
+    idx.search(q[:8], 10)                                          # few queries: the exact kernels, no image
+    idx.set_option("split", "0")
+    idx.search(q, 10)                                              # many queries with the prefilter off: still none
+    torch.cuda.synchronize()
+    used_exact = free0 - torch.cuda.mem_get_info()[0]
+    corpus = 200000 * 768 * 4
+    assert used_exact < corpus * 1.4, (used_exact, corpus)          # tiles + staging / workspaces (~170 MB); with an image: >= 1.5 x + those
+    idx.set_option("split", "1")
+    D, I = idx.search(q, 100)
+    assert idx.last_plan().startswith("split:")
+    torch.cuda.synchronize()
+    used_split = free0 - torch.cuda.mem_get_info()[0]
+    assert used_split > used_exact + corpus * 0.45, (used_split, used_exact)
+    assert_same(D, I, *oracle.flat_ip_search(x[:200000], q, 100))
+    idx.add(x[200000:200037])                                      # into the tail group of the segment that owns an image
+    idx.add(x[200037:])                                            # ... and a new segment without one
+    D, I = idx.search(q, 100)
+    assert idx.last_plan().startswith("split:")
+    sel = np.arange(0, 96, 6)
+    assert_same(D[sel], I[sel], *oracle.flat_ip_search(x, q[sel], 100))
+    idx.set_option("split", "0")
+    D0, I0 = idx.search(q, 100)
+    assert_same(D, I, D0, I0)
