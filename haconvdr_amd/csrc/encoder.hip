@@ -1202,6 +1202,40 @@ __global__ __launch_bounds__(256) void cls_head_kernel(const float *__restrict__
     }
 }
 
+// Last layer, large-batch path: the query projection of the <s> rows only (the other rows' queries are never used: the
+// attention kernel runs the first query block of each sequence and only its row 0 is kept).  Same arithmetic as the QKV GEMM's
+// epilogue -- q = rstd (y . W'q^T - mean wsum) + cvec on the bf16 row y and the folded weights -- in fp32, written into row
+// off[b] of the big Q matrix.  Eight sequences per workgroup share each read of a weight row.
+__global__ __launch_bounds__(256) void cls_q_kernel(const bf16 *__restrict__ yb, const float2 *__restrict__ stats, SeqInfo s, int B,
+                                                    const bf16 *__restrict__ Wq, const float *__restrict__ wsum, const float *__restrict__ cvec,
+                                                    bf16 *__restrict__ q) {
+    __shared__ float xs[CLS_SB][H];
+    __shared__ float2 st[CLS_SB];
+    const int b0 = blockIdx.x * CLS_SB, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nb = min(CLS_SB, B - b0);
+    for (int j = 0; j < CLS_SB; ++j) {
+        const size_t row = (size_t)s.off[min(b0 + j, B - 1)];
+        for (int i = tid; i < H; i += 256) xs[j][i] = j < nb ? (float)yb[row * H + i] : 0.f;
+        if (tid == 0) st[j] = stats[row];
+    }
+    __syncthreads();
+    for (int n = w; n < H; n += 4) {
+        const bf16 *wr = Wq + (size_t)n * H;
+        float wv[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) wv[i] = (float)wr[lane + 64 * i];
+        const float ws = wsum[n], cv = cvec[n];
+#pragma unroll
+        for (int j = 0; j < CLS_SB; ++j) {
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) acc = fmaf(wv[i], xs[j][lane + 64 * i], acc);
+            acc = wave_sum(acc);
+            if (lane == 0 && j < nb) q[(size_t)s.off[b0 + j] * H + n] = (bf16)(st[j].y * (acc - st[j].x * ws) + cv);
+        }
+    }
+}
+
 __global__ void f32_to_bf16_kernel(const float *__restrict__ src, bf16 *__restrict__ dst, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = (bf16)src[i];
@@ -1423,7 +1457,11 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
             HAC_TRY(prof_begin(e, 1 + HAC_ENC_CLASS_QKV, st));
             g8a.A = xb; g8a.K = H; g8a.astats = li ? statsF : idstats;
             g8a.W = w.wqkv8; g8a.N = 3 * H; g8a.wsum = w.fold; g8a.cvec = w.fold + 3 * H; g8a.q = q; g8a.k = k; g8a.v16 = vt;
+            // last layer: keys and values of every row, queries of the <s> rows only (a third of the GEMM: 0.6 ms per 1000 x 512 forward)
+            g8a.n_tile0 = last ? H / 256 : 0;
             launch8(epi_qkv, 0);
+            g8a.n_tile0 = 0;
+            if (last) cls_q_kernel<<<dim3((unsigned)((B + CLS_SB - 1) / CLS_SB)), dim3(256), 0, st>>>(xb, g8a.astats, s, B, w.wqkv8, w.fold, w.fold + 3 * H, q);
             HAC_TRY(prof_end(e, 1 + HAC_ENC_CLASS_QKV, st));
         } else {
             g.A = xb; g.W = w.wqkv; g.bias = w.bqkv; g.N = 3 * H; g.K = H; g.q = q; g.k = k; g.v16 = vt;

@@ -17,7 +17,7 @@ def main():
     from haconvdr_amd.encoder import ANCEEncoder
     name, values = sys.argv[1], sys.argv[2:]
     rounds = 3
-    if len(values) > 2 and values[-1].startswith("r="):
+    if values and values[-1].startswith("r="):
         rounds = int(values.pop()[2:])
     enc = ANCEEncoder.from_state_dict(synth.ance_state_dict(0xA11CE, 12, rich=False))
     tok, _ = synth.token_batch(0x70C, 1000, 512, fixed_len=512)
