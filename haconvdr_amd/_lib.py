@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libhaconvdr.so")
+# HAC_LIBRARY_PATH: development only (A/B runs of kernel variants built beside the tree); the product is the in-tree library
+LIB_PATH = os.environ.get("HAC_LIBRARY_PATH") or os.path.join(_HERE, "csrc", "libhaconvdr.so")
 _LIB = None
 
 HAC_MAX_K = 2048
