@@ -315,7 +315,7 @@ def main():
         roofline = {"kernel": "gemm8_kernel<EPI8_GELU> (FFN-up 768->3072: folded LayerNorm + bias + erf-GELU fused)", "bound": "mfma",
                     "achieved": round(tf, 1), "peak": PEAK_F16_MFMA_TF, "unit": "TFLOP/s", "frac": round(tf / PEAK_F16_MFMA_TF, 4),
                     "traffic": pmc("ffn_up_hbm_bytes_per_launch") if world == 1 else None,
-                    "mfma_util": mfma_util("gemm8_kernel<3>") if world == 1 else None,
+                    "mfma_util": mfma_util("gemm8_kernel<3,") if world == 1 else None,
                     "kernel_ms": round(avg_ms, 4), "launches_per_step": n_launch // args.steps, "flops_per_launch": fl_launch,
                     "share_of_step": round(avg_ms * (n_launch / args.steps) / ms_per_step, 3),
                     "encoder_stack": {"ms_per_step": round(stack_avg, 3), "achieved_TFLOPs": round(enc_flops / (stack_avg * 1e-3) / 1e12, 1),

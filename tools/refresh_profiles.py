@@ -77,7 +77,7 @@ def main():
         r = max(c["hbm_read_bytes_per_launch"] for c in fr)
         ww = max(c["hbm_write_bytes_per_launch"] for c in wr)
         return {"read": int(r), "write": int(ww), "total": int(r + ww)}
-    t = traffic("gemm8_kernel<3>")
+    t = traffic("gemm8_kernel<3,")
     if t:
         out["ffn_up_hbm_bytes_per_launch"] = t["total"]
         out["ffn_up"] = t
@@ -85,7 +85,8 @@ def main():
     if t:
         out["search_hbm_bytes_per_launch"] = t["total"]
         out["search"] = t
-    for name, needle in (("qkv", "gemm8_kernel<0>"), ("resid", "gemm8_kernel<2>"), ("attention", "attention_stream_kernel<16>"),
+    for name, needle in (("qkv", "gemm8_kernel<0,"), ("out_proj", "gemm8_kernel<2, false>"), ("ffn_down", "gemm8_kernel<2, true>"),
+                         ("attention", "attention_stream_kernel<16>"),
                          ("rescore", "rescore_kernel")):
         t = traffic(needle)
         if t:
