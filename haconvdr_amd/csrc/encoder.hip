@@ -1278,9 +1278,10 @@ struct hac_encoder {
     size_t idstats_rows = 0;
     int attn_mode = 0;                    // 0: streaming single-pass attention; 1: two-pass kernels (cross-check)
     int gemm_mode = -1;                   // -1: by size, 0: classic kernels only, 1: gemm8 whenever the batch has a full tile (tests)
-    // gemm8 loop form per class (bit 0 QKV, 1 out-proj, 2 FFN-up, 3 FFN-down; 1 = SPLIT).  A/B in one process on the 1000 x 512
-    // forward (tools/ab_encoder.py): SPLIT -1 % on QKV and -3.4 % on FFN-down (K = 3072), +3 % on out-proj, +1 % on FFN-up
-    int g8_split = 9;
+    // gemm8 loop form per class (bit 0 QKV, 1 out-proj, 2 FFN-up, 3 FFN-down; 1 = SPLIT, 0 = round 2's loop, kept for A/B runs).
+    // A/B in one process on the 1000 x 512 forward (tools/ab_encoder.py), two boxes: SPLIT -1 .. -3.4 % on FFN-down (K = 3072),
+    // +-1 % (inside the run-to-run spread) on the K = 768 GEMMs; layer stack 93.4 - 94.9 ms with every class split vs 95.3 - 96.7 with none
+    int g8_split = 15;
     void *h_pin = nullptr;
     size_t h_pin_bytes = 0;
     int *h_len = nullptr;      // pinned: padded lengths of a forward that runs as several sub-batches
