@@ -1144,23 +1144,25 @@ __global__ __launch_bounds__(256) void gather_cls_kernel(const bf16 *__restrict_
 }
 
 // ------------------------------------------------------------------ ANCE head: out[b] = LN(W_h . x[row_b] + b_h)   (fp32)
-constexpr int CLS_SB = 8;   // sequences per workgroup of the head: every row of W_h is read once per 8 sequences, not once per sequence
-__global__ __launch_bounds__(256) void cls_head_kernel(const float *__restrict__ x, SeqInfo s, int compact, int B, const float *__restrict__ Wh,
-                                                       const float *__restrict__ bh, const float *__restrict__ gamma,
-                                                       const float *__restrict__ beta, float eps, float *__restrict__ out) {
+constexpr int CLS_SB = 8;     // sequences per workgroup of the <s>-row projections: a weight row is read once per 8 sequences
+constexpr int CLS_NS = 64;    // output features per workgroup (16 per wave): grid = (ceil(B / 8), 768 / 64)
+// The two 768 x 768 projections that run on the <s> rows only (the ANCE head and the last layer's queries) are tiny (1.2 GFLOP
+// per 1000 sequences) but were 0.43 - 0.45 ms per launch as one workgroup per 8 sequences walking all 768 weight rows (64
+// workgroups, 192 dependent iterations per wave: rocprofv3, r03).  Dealt as (8 sequences) x (64 features) they take tens of
+// microseconds.  A sequence's arithmetic (products, their order, the reduction) does not depend on its neighbours.
+
+// ANCE head, first half: e[b][n] = W_h[n,:] . x[b,:] + b_h[n] in fp32 (models.py:43)
+__global__ __launch_bounds__(256) void cls_head_proj_kernel(const float *__restrict__ x, SeqInfo s, int compact, int B, const float *__restrict__ Wh,
+                                                            const float *__restrict__ bh, float *__restrict__ e_out) {
     __shared__ float xs[CLS_SB][H];
-    __shared__ float es[CLS_SB][H];
-    __shared__ float red[8];
-    const int b0 = blockIdx.x * CLS_SB, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b0 = blockIdx.x * CLS_SB, n0 = blockIdx.y * CLS_NS, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nb = min(CLS_SB, B - b0);
     for (int j = 0; j < CLS_SB; ++j) {
         const float *xr = x + (size_t)(compact ? b0 + j : s.off[min(b0 + j, B - 1)]) * H;
         for (int i = tid; i < H; i += 256) xs[j][i] = j < nb ? xr[i] : 0.f;
     }
     __syncthreads();
-    // each wave computes 192 outputs per sequence; a wave reads one weight row at a time (coalesced) and reduces.  The
-    // arithmetic of a sequence (products, their order, the reduction) does not depend on its neighbours.
-    for (int n = w; n < H; n += 4) {
+    for (int n = n0 + w; n < n0 + CLS_NS; n += 4) {
         const float *wr = Wh + (size_t)n * H;
         float wv[12];
 #pragma unroll
@@ -1172,46 +1174,56 @@ __global__ __launch_bounds__(256) void cls_head_kernel(const float *__restrict__
 #pragma unroll
             for (int i = 0; i < 12; ++i) acc = fmaf(wv[i], xs[j][lane + 64 * i], acc);
             acc = wave_sum(acc);
-            if (lane == 0) es[j][n] = acc + bias;
+            if (lane == 0 && j < nb) e_out[(size_t)(b0 + j) * H + n] = acc + bias;
         }
     }
+}
+
+// ANCE head, second half: out[b] = LayerNorm_768(e[b]) (models.py:44); a sequence the device could not encode gets a NaN row
+__global__ __launch_bounds__(256) void cls_head_norm_kernel(const float *__restrict__ e_in, SeqInfo s, const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, float eps, float *__restrict__ out) {
+    __shared__ float red[8];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float *er = e_in + (size_t)b * H;
+    float v[3];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        v[i] = er[tid + 256 * i];
+        sum += v[i];
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[w] = sum;
     __syncthreads();
-    for (int j = 0; j < nb; ++j) {
-        const int b = b0 + j;
-        float sum = 0.f;
-        for (int i = tid; i < H; i += 256) sum += es[j][i];
-        sum = wave_sum(sum);
-        if (lane == 0) red[w] = sum;
-        __syncthreads();
-        const float mean = (red[0] + red[1] + red[2] + red[3]) * (1.0f / H);
-        float q = 0.f;
-        for (int i = tid; i < H; i += 256) {
-            const float d = es[j][i] - mean;
-            q += d * d;
-        }
-        q = wave_sum(q);
-        if (lane == 0) red[4 + w] = q;
-        __syncthreads();
-        const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) * (1.0f / H) + eps);
-        const bool bad = s.err[b] != 0;
-        for (int i = tid; i < H; i += 256) {
-            const float v = (es[j][i] - mean) * rstd * gamma[i] + beta[i];
-            out[(size_t)b * H + i] = bad ? NAN : v;  // unsupported mask or token id of THIS sequence: fail loudly, never guess
-        }
-        __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) * (1.0f / H);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float d = v[i] - mean;
+        q += d * d;
+    }
+    q = wave_sum(q);
+    if (lane == 0) red[4 + w] = q;
+    __syncthreads();
+    const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) * (1.0f / H) + eps);
+    const bool bad = s.err[b] != 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = tid + 256 * i;
+        out[(size_t)b * H + c] = bad ? NAN : (v[i] - mean) * rstd * gamma[c] + beta[c];   // unsupported mask or token id of THIS sequence: fail loudly, never guess
     }
 }
 
 // Last layer, large-batch path: the query projection of the <s> rows only (the other rows' queries are never used: the
 // attention kernel runs the first query block of each sequence and only its row 0 is kept).  Same arithmetic as the QKV GEMM's
 // epilogue -- q = rstd (y . W'q^T - mean wsum) + cvec on the bf16 row y and the folded weights -- in fp32, written into row
-// off[b] of the big Q matrix.  Eight sequences per workgroup share each read of a weight row.
+// off[b] of the big Q matrix.
 __global__ __launch_bounds__(256) void cls_q_kernel(const bf16 *__restrict__ yb, const float2 *__restrict__ stats, SeqInfo s, int B,
                                                     const bf16 *__restrict__ Wq, const float *__restrict__ wsum, const float *__restrict__ cvec,
                                                     bf16 *__restrict__ q) {
     __shared__ float xs[CLS_SB][H];
     __shared__ float2 st[CLS_SB];
-    const int b0 = blockIdx.x * CLS_SB, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b0 = blockIdx.x * CLS_SB, n0 = blockIdx.y * CLS_NS, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nb = min(CLS_SB, B - b0);
     for (int j = 0; j < CLS_SB; ++j) {
         const size_t row = (size_t)s.off[min(b0 + j, B - 1)];
@@ -1219,7 +1231,7 @@ __global__ __launch_bounds__(256) void cls_q_kernel(const bf16 *__restrict__ yb,
         if (tid == 0) st[j] = stats[row];
     }
     __syncthreads();
-    for (int n = w; n < H; n += 4) {
+    for (int n = n0 + w; n < n0 + CLS_NS; n += 4) {
         const bf16 *wr = Wq + (size_t)n * H;
         float wv[12];
 #pragma unroll
@@ -1462,7 +1474,7 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
             g8a.n_tile0 = last ? H / 256 : 0;
             launch8(epi_qkv, 0);
             g8a.n_tile0 = 0;
-            if (last) cls_q_kernel<<<dim3((unsigned)((B + CLS_SB - 1) / CLS_SB)), dim3(256), 0, st>>>(xb, g8a.astats, s, B, w.wqkv8, w.fold, w.fold + 3 * H, q);
+            if (last) cls_q_kernel<<<dim3((unsigned)((B + CLS_SB - 1) / CLS_SB), H / CLS_NS), dim3(256), 0, st>>>(xb, g8a.astats, s, B, w.wqkv8, w.fold, w.fold + 3 * H, q);
             HAC_TRY(prof_end(e, 1 + HAC_ENC_CLASS_QKV, st));
         } else {
             g.A = xb; g.W = w.wqkv; g.bias = w.bqkv; g.N = 3 * H; g.K = H; g.q = q; g.k = k; g.v16 = vt;
@@ -1546,7 +1558,9 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
     }
 #undef HAC_GEMM
     HAC_TRY(prof_end(e, 0, st));
-    cls_head_kernel<<<dim3((unsigned)((B + CLS_SB - 1) / CLS_SB)), dim3(256), 0, st>>>(x_c, s, 1, B, e->wh, e->bh, e->ng, e->nb, 1e-5f, out_dev);
+    // ANCE head on the compact <s> rows: projection (y_c is free again), then LayerNorm_768 and the per-sequence error flag
+    cls_head_proj_kernel<<<dim3((unsigned)((B + CLS_SB - 1) / CLS_SB), H / CLS_NS), dim3(256), 0, st>>>(x_c, s, 1, B, e->wh, e->bh, y_c);
+    cls_head_norm_kernel<<<dim3((unsigned)B), dim3(256), 0, st>>>(y_c, s, e->ng, e->nb, 1e-5f, out_dev);
     HAC_HIP(hipGetLastError());
     e->plan_sub_batches += 1;
     e->plan_rows += Mp;

@@ -187,7 +187,9 @@ int hac_encoder_forward_device(hac_encoder *enc, const void *ids_dev, const void
  * kernels with separate LayerNorm passes) | "8phase" (the large-batch ping-pong kernel with folded LayerNorms whenever
  * the batch has a whole 256-row tile); "attn" = "stream" (persistent single-pass attention kernels, the default) |
  * "twopass" (one workgroup per (sequence, head), exact row maxima first: the cross-check of the tests);
- * "max_tokens" = packed rows per sub-batch (integer >= 4096).  Any other name or value is HAC_ERR_INVALID (never a
+ * "max_tokens" = packed rows per sub-batch (integer >= 4096); "g8_split" = bit mask 0..15 (development: which kernel
+ * classes -- bit 0 QKV, 1 out-proj, 2 FFN-up, 3 FFN-down -- run the operand-split loop of the large-batch GEMM, default
+ * 15; 0 = round 2's loop: same results bit for bit).  Any other name or value is HAC_ERR_INVALID (never a
  * silent default).  HAC_ENC_GEMM gives the default of "gemm" and is read once, in hac_encoder_create.
  * "auto" decides ONCE per forward call, from the rows of the whole batch: every sub-batch of a call runs the same
  * GEMM family, so a sequence's embedding does not depend on the sub-batch it fell into. */
