@@ -1305,7 +1305,8 @@ struct hac_encoder {
         std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
         size_t used = 0;
     } pools[1 + HAC_ENC_NCLASS];
-    long max_tokens = 262144;  // packed rows per sub-batch (workspaces: ~4.5 GB; 131072 is 2 % slower, 524288 no faster)
+    long max_tokens = 524288;  // packed rows per sub-batch (workspaces: ~9 GB).  1000 x 512 then runs as ONE pass: no host read-back of the
+                               // lengths at all, -0.6 % against two passes of 262144 with round 3's kernels (196608: +0.9 %)
     int n_cu = 256;
     // what the most recent forward ran (hac_encoder_last_plan)
     const char *plan_gemm = "none";

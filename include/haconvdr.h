@@ -176,7 +176,7 @@ int hac_encoder_finalize(hac_encoder *enc);
 int hac_encoder_forward(hac_encoder *enc, const int32_t *ids, const int32_t *mask, int B, int L, float *out);
 /* Device/stream variant: ids/mask device pointers of elem_bytes 4 (int32) or 8 (int64, what the
  * reference passes); out_dev float32 [B,768].  Work is enqueued on hip_stream.  A batch of more than
- * 262144 padded rows (B * roundup(L,32)) runs as several sub-batches sized by the real lengths: that
+ * 524288 padded rows (B * roundup(L,32); option "max_tokens") runs as several sub-batches sized by the real lengths: that
  * costs ONE read-back of B ints, i.e. the call synchronizes hip_stream once (not capturable); smaller
  * batches never synchronize.  Errors the device finds are reported per sequence: a mask that is not
  * a non-empty prefix mask, or an attended token id outside [0, vocab) (nn.Embedding would raise),

@@ -417,7 +417,8 @@ def test_cfg5_shape_varlen_auto_routed_vs_oracle():
 
 
 def test_two_sub_batches_auto_routed_vs_oracle_and_small_tail():
-    """520 x 512 full-length queries = 266,240 rows: a 512-sequence sub-batch and an 8-sequence tail.  The GEMM family is
+    """520 x 512 full-length queries = 266,240 rows with 262,144 rows per sub-batch (max_tokens; the default is twice that):
+    a 512-sequence sub-batch and an 8-sequence tail.  The GEMM family is
     decided once per call (the tail used to take the classic fp32-residual kernels while the rest took gemm8),
     so the tail's embeddings equal, bit for bit, the same sequences encoded at the head of a large batch; rows on either
     side of the sub-batch border against the oracle."""
@@ -426,8 +427,12 @@ def test_two_sub_batches_auto_routed_vs_oracle_and_small_tail():
     enc = _enc12()
     ids, _ = synth.token_batch(0x5B, 520, 512, fixed_len=512)
     mask = np.ones_like(ids)
-    out = enc(ids, mask)
-    plan = _plan(enc)
+    enc.set_option("max_tokens", "262144")     # sub-batch sizing only: the kernel routing stays automatic
+    try:
+        out = enc(ids, mask)
+        plan = _plan(enc)
+    finally:
+        enc.set_option("max_tokens", "524288")
     assert plan["gemm"] == "gemm8" and plan["sub_batches"] == "2", plan
     pick = [0, 511, 512, 519]
     ref = ance_oracle.ance_forward(_sd12(), ids[pick], mask[pick])
