@@ -196,3 +196,36 @@ def test_run_test_is_the_references_main(chain_dir, tmp_path, monkeypatch):
             f.write(f"{qid}\t0\t{top}\t1\n")
     res = queries.run_test(args)
     assert res["MRR"] == 100.0 and res["Recall@10"] == 100.0
+
+
+@pytest.mark.gpu
+def test_topiocqa_chain_vs_oracle(chain_dir, tmp_path, monkeypatch):
+    """The TopiOCQA form of the chain (src/test_HAConvDR_topiocqa.py: Retrieval_topiocqa, test_type convqp, max_concat_length
+    512).  That script cannot be imported (it imports a class that does not exist), so no fixture of the reference's
+    run exists; its dataset class is pinned by tests/golden/queries (test_query_construction.py) and the chain is checked
+    against the oracle here: embeddings of the constructed queries, retrieval over the same blocks, TREC lines."""
+    import torch
+    from haconvdr_amd import queries, query_construction as qc
+    from oracle import ance_oracle, oracle as orc
+    tmp, sd, x, offset2pid = chain_dir
+    monkeypatch.setattr(queries, "_load_tokenizer", lambda path: StubTokenizer())
+    args = _args(tmp)
+    args.dataset = "topiocqa"
+    args.test_file_path = os.path.join(HERE, "golden", "queries", "topiocqa_test.jsonl")
+    args.test_type, args.max_concat_length, args.max_doc_length, args.max_response_length = "convqp", 512, 384, 32
+    args.qrel_output_path = str(tmp_path)
+    emb, e2id = queries.get_test_query_embedding(args)
+    ds = qc.Retrieval_topiocqa(args, StubTokenizer(), args.test_file_path)
+    batch = ds.get_collate_fn(args)([ds[i] for i in range(len(ds))])
+    assert list(batch["bt_sample_ids"]) == list(e2id) and emb.shape == (len(ds), 768)
+    ref = ance_oracle.ance_forward(sd, batch["bt_conv_qp"].numpy(), batch["bt_conv_qp_mask"].numpy())
+    assert _cosd(emb, ref).max() < 2e-4
+    path = queries.run_test(args)
+    lines = [ln.split() for ln in open(path).read().splitlines()]
+    assert len(lines) == len(ds) * TOPK and lines[0][1] == "Q0" and lines[0][-1] == "ance"
+    oD, oI = orc.flat_ip_search(x, emb, TOPK)                       # the product's own embeddings: ids must be the oracle's
+    first_pid = {}
+    for ln in lines:
+        first_pid.setdefault(ln[0], ln[2])
+    for row, qid in enumerate(dict.fromkeys(e2id)):
+        assert first_pid[qid] == str(offset2pid[int(oI[row, 0])]), (qid, first_pid[qid])
