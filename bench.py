@@ -403,6 +403,21 @@ def main():
                                         "what": f"same step over a {NORTH_STAR_ROWS}x768 corpus on {world} GPU(s) ({hi2 - lo2} rows per GPU); "
                                                 "BASELINE.json north_star target: >= 3000 queries/s on 8 GPUs"}
             del idx2, srch2
+        if world == 1 and enc is not None and rows == CFG3_ROWS:
+            # BASELINE configs[3] on ONE of its eight ranks, part by part (the 8-GPU run is the driver's): encode 1000 / 8
+            # queries, search all 1000 over a 6.75M-row shard.  The two all-gathers between them (3 MB of embeddings, 0.8 MB
+            # of packed keys per rank) are not in these figures.
+            idx4 = FlatIPIndex(D_EMB, devices=(local_rank,))
+            fill_index(idx4, 0, CFG4_SHARD_ROWS, dev, -(-CFG4_SHARD_ROWS // CFG3_BLOCKS))
+            n8 = nq // 8
+            t_e8 = timed(lambda: enc(ids_t[:n8], mask_t[:n8]), 5, sync)
+            emb8 = enc(ids_t, mask_t)
+            t_s8 = timed(lambda: ShardedSearcher(idx4, shard_base=0).search(emb8, k), 5, sync)
+            extras["cfg4_one_rank_parts"] = {"encode_ms": round(t_e8 * 1e3, 3), "encode_queries": n8, "search_ms": round(t_s8 * 1e3, 3),
+                                             "shard_rows": CFG4_SHARD_ROWS, "sum_ms": round((t_e8 + t_s8) * 1e3, 3),
+                                             "what": "one rank's work of the N = 8 step (54M-row corpus): NOT a measurement of the 8-GPU step, "
+                                                     "which adds two small all-gathers and is the driver's to run"}
+            del idx4
         if world == 1:
             extras.update(single_gpu_extras(np, torch, synth, FlatIPIndex, enc, index, q_pre, dev, n_local, nq, k, sync))
         elif enc is not None:
