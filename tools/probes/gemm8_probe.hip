@@ -48,6 +48,11 @@ int main(){
     g.N=c.N; g.K=c.K; g.n_groups = c.epi==EPI8_GELU ? 2 : 1; float t=0, t0=0;
     if(c.epi==EPI8_QKV) t=run<EPI8_QKV>(g,5,&t0); if(c.epi==EPI8_RESID) t=run<EPI8_RESID>(g,5,&t0); if(c.epi==EPI8_GELU) t=run<EPI8_GELU>(g,5,&t0);
     printf("%s : split %.3f ms %.0f TF | round-2 form %.3f ms %.0f TF\n", c.name, t, 2.0*M*c.N*c.K/t/1e9, t0, 2.0*M*c.N*c.K/t0/1e9);
+#ifdef G8_NGSWEEP
+    for (int ng : {1, 2, 4}) { if ((c.N / 256) % ng) continue; Gemm8Args gg = g; gg.n_groups = ng; float a0 = 0, a1 = 0;
+      if(c.epi==EPI8_QKV) a1=run<EPI8_QKV>(gg,5,&a0); if(c.epi==EPI8_RESID) a1=run<EPI8_RESID>(gg,5,&a0); if(c.epi==EPI8_GELU) a1=run<EPI8_GELU>(gg,5,&a0);
+      printf("   n_groups %d: split %.3f ms\n", ng, a1); }
+#endif
     {   // same bits from both forms (same MFMA order per output element)
       const size_t nb = c.epi==EPI8_GELU ? (size_t)M*3072*2 : (size_t)M*768*2; bf16* out = c.epi==EPI8_GELU ? h : (c.epi==EPI8_RESID ? yb : k);
       std::vector<unsigned short> a(nb/2), b(nb/2);
