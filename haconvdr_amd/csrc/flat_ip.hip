@@ -2070,3 +2070,9 @@ int hac_index_profile_drain(hac_index *idx, float *ms_out, int cap, int *n_out) 
 }
 
 }  // extern "C"
+
+#ifdef SH_STAMP
+extern "C" int hac_debug_scan_stamps(unsigned long long *out) {   // development builds only (tools/ab_search.py)
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(hac::g_sh_stamps), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
