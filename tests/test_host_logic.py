@@ -232,3 +232,26 @@ def test_streaming_attention_kernels_keep_everything_in_registers():
         assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1)) == 0, b[:200]
         assert int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1)) == 4
     assert seen == 2
+
+
+def test_prefilter_scan_kernels_keep_everything_in_registers_and_fit_the_lds():
+    """scanh_kernel sits at 248 of 256 VGPRs behind a counted LDS-DMA stream: several variants of round 3 spilled (a scratch
+    reload inside the k-loop drains the DMA look-ahead, one around it costs a round trip per round).  No instantiation may
+    spill, and the one-product form's LDS budget (query buffers, corpus rings, lists' bookkeeping, the staging / sort
+    scratch of its own) must fit the 160 KiB of a CU."""
+    path = os.path.join(ROOT, "haconvdr_amd", "csrc", "flat_ip.resources.txt")
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(path)])
+    blocks = re.split(r"remark: Function Name: ", open(path).read())
+    seen = 0
+    for b in blocks:
+        if "scanh_kernel" not in b.split("\n", 1)[0]:
+            continue
+        seen += 1
+        assert int(re.search(r"VGPRs: (\d+)", b).group(1)) <= 256
+        assert int(re.search(r"VGPRs Spill: (\d+)", b).group(1)) == 0, b[:200]
+        assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1)) == 0, b[:200]
+        assert int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1)) == 2
+    assert seen == 4          # <1,false>, <1,true>, <3,false>, <3,true>
+    src = open(os.path.join(ROOT, "haconvdr_amd", "csrc", "scan_split.inc")).read()
+    assert "static_assert(LDS <= 163840" in src
