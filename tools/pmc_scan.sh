@@ -8,7 +8,7 @@ v=$1; shift
 i=0
 for set in "$@"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmcscan_${v}_$i -- python3 $R/tools/ab_search.py 10000000 2 > $R/gpurun_out/pmcscan_${v}_$i.log 2>&1 || tail -5 $R/gpurun_out/pmcscan_${v}_$i.log
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmcscan_${v}_$i -- python3 $R/tools/ab_search.py ${ROWS:-10000000} 2 > $R/gpurun_out/pmcscan_${v}_$i.log 2>&1 || tail -5 $R/gpurun_out/pmcscan_${v}_$i.log
 done
 python3 - <<PY
 import csv, glob, collections
