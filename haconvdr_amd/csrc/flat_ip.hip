@@ -497,7 +497,10 @@ __global__ __launch_bounds__(W * 64) void scanq_kernel(ScanArgs a) {
 
     for (int i = tid; i < NQ; i += NTHR) {
         cnt[i] = 0;
-        thr[i] = i < NQr ? (a.thr_init ? a.thr_init[q0 + i] : -INFINITY) : INFINITY;  // padded queries admit nothing
+        // padded queries admit nothing: NaN, not +inf -- a padded row is whatever the caller's buffer holds behind the count
+        // (device-decided fallback), its scores can be +inf, +inf >= +inf passes, and the lists of padded queries are never
+        // compacted: the overflow loop then never ends (found by a soak run; tests: stale fallback rows)
+        thr[i] = i < NQr ? (a.thr_init ? a.thr_init[q0 + i] : -INFINITY) : __builtin_nanf("");
     }
     if (tid == 0) *ovf = 0;
 #pragma unroll

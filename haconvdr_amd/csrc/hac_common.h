@@ -63,6 +63,12 @@ struct GrowBuf {
         }
         if (e != hipSuccess) return fail(HAC_ERR_OOM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
         cap = want;
+        // A new buffer starts out as zeros, whatever the allocator recycled: several workspaces are sized for a capacity and
+        // filled up to a count that lives on the device, and what lies beyond the count must not depend on the process's
+        // history (a soak run of 2400 index lifetimes hung in the device-decided fallback on recycled memory; fresh pages,
+        // which is what a first search sees, are zero).  Growth is rare; the wait keeps the fill ahead of every stream.
+        if (hipMemset(p, 0, want) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess)
+            return fail(HAC_ERR_OOM, "hipMemset(%zu) of a new workspace failed", want);
         return HAC_OK;
     }
     void release() {

@@ -944,3 +944,40 @@ def test_half_precision_image_is_built_lazily(oracle):
     idx.set_option("split", "0")
     D0, I0 = idx.search(q, 100)
     assert_same(D, I, D0, I0)
+
+
+@pytest.mark.gpu
+def test_device_decided_fallback_ignores_stale_rows_behind_the_count(oracle):
+    """The device-decided fallback gathers the failed queries into a buffer sized for all nq and searches whole 32-query
+    tiles of it.  Rows behind the device-side count used to keep what an earlier search (or the allocator) left there: after a
+    search whose queries all failed their certificates with values near FLT_MAX, the next search with ONE failing query hung in
+    the exact kernels (scores of +inf passed the +inf threshold of the padded queries, whose lists are never compacted).
+    Found by a soak run over 2400 index lifetimes; rows behind the count are zeroed now and padded thresholds are NaN."""
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent("""
+        import sys, torch
+        sys.path.insert(0, %r)
+        from haconvdr_amd.index import FlatIPIndex
+        g = torch.Generator(device="cuda").manual_seed(785672694)
+        n, nq, k = 400_000, 130, 100
+        _ = torch.randn((n, 768), generator=g, device="cuda")
+        x = torch.randn((n, 8), generator=g, device="cuda") @ torch.randn((8, 768), generator=g, device="cuda")   # rank 8: near-ties
+        q = torch.randn((nq, 768), generator=g, device="cuda")
+        idx = FlatIPIndex(768); idx.set_option("split", "1"); idx.set_option("split_decide", "device")
+        idx.add_tensor(x[:250_000]); idx.add_tensor(x[250_000:])
+        idx.search_tensor(torch.full((nq, 768), 3.3e38, device="cuda"), k); torch.cuda.synchronize()
+        assert "fallback=130/130" in idx.last_plan(), idx.last_plan()
+        D, I = idx.search_tensor(q, k); torch.cuda.synchronize()
+        plan = idx.last_plan()
+        ref = FlatIPIndex(768); ref.set_option("split", "0")
+        ref.add_tensor(x[:250_000]); ref.add_tensor(x[250_000:])
+        D0, I0 = ref.search_tensor(q, k); torch.cuda.synchronize()
+        assert torch.equal(I, I0) and torch.equal(D, D0)
+        print("PLAN", plan)
+    """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    # a child process with a time limit: the failure mode is a kernel that never ends
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "fallback=1/130" in r.stdout, r.stdout   # the case really takes the fallback with one live query

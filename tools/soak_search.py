@@ -1,0 +1,46 @@
+"""Development: soak of the search -- the prefilter path (split=1) against the exact fp32 kernels (split=0) over random corpora, query sets and
+value ranges, a fresh index per case (every lifetime recycles device memory): bit-exact ids and scores, progress every 5 cases.
+  python tools/soak_search.py [seed] [seconds]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from haconvdr_amd.index import FlatIPIndex
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+budget = float(sys.argv[2]) if len(sys.argv) > 2 else 240.0
+t0 = time.time(); n_cases = 0; n_split = 0
+while time.time() - t0 < budget:
+    n = int(rng.choice([20_000, 50_001, 130_000, 400_000, 1_000_000]))
+    nq = int(rng.choice([1, 40, 130, 257, 1000, 1500]))
+    k = int(rng.choice([1, 10, 100, 200]))
+    kind = rng.choice(["gauss", "dups", "scaled", "lowrank"])
+    g = torch.Generator(device="cuda").manual_seed(int(rng.integers(1 << 30)))
+    x = torch.randn((n, 768), generator=g, device="cuda")
+    if kind == "dups":
+        x[n // 2:] = x[: n - n // 2].clone()
+    elif kind == "scaled":
+        x *= torch.rand((n, 1), generator=g, device="cuda") * 4
+    elif kind == "lowrank":
+        x = torch.randn((n, 8), generator=g, device="cuda") @ torch.randn((8, 768), generator=g, device="cuda")
+    q = torch.randn((nq, 768), generator=g, device="cuda")
+    res = []
+    for split in ("1", "0"):
+        idx = FlatIPIndex(768)
+        idx.set_option("split", split)
+        for i in range(0, n, 250_000):
+            idx.add_tensor(x[i:i + 250_000])
+        D, I = idx.search_tensor(q, k)
+        torch.cuda.synchronize()
+        res.append((D.clone(), I.clone(), idx.last_plan()))
+        del idx
+    ok = torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][0], res[1][0])
+    n_cases += 1
+    if n_cases % 5 == 0:
+        print(f'{n_cases} cases ok, {time.time() - t0:.0f} s', flush=True)
+    n_split += res[0][2].startswith("split:")
+    if not ok:
+        bad = (res[0][1] != res[1][1]).nonzero()
+        print("MISMATCH", n, nq, k, kind, bad[:5].tolist(), res[0][2], flush=True)
+        sys.exit(1)
+print(f"soak ok: {n_cases} cases ({n_split} through the prefilter) in {time.time() - t0:.0f} s", flush=True)
