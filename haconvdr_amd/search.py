@@ -6,6 +6,13 @@ passage ids, global top-``topN`` in the first ``topN`` columns, earlier block wi
 score ties), but the per-block python merge (:111-149) is replaced by keeping every
 block resident in HBM and running ONE exact top-k over all of them, with the
 ``passage_embedding2id[I]`` remap (:110) fused into the result kernel.
+
+Shape of the result.  The reference's merge loop appends BOTH lists' leftovers (:144-149), so with two or more
+blocks it returns ``(nq, 2*topN)``: the global top-``topN`` followed by what is left of {top-``topN`` of blocks
+0..B-2, top-``topN`` of block B-1} in merge order; its consumers slice ``[:topN]`` (:238-239).  By default this
+module returns the ``(nq, topN)`` that is read; ``reference_shape=True`` returns the reference's literal matrix
+(every column equal to the reference's, tested against the goldens' full ``ref_D`` / ``ref_I``) at the price of
+a second search (the last block on its own).
 """
 import logging
 import os
@@ -29,23 +36,23 @@ def iter_embedding_blocks(passage_embeddings_dir, passage_block_num, mmap=True):
         yield emb, np.asarray(ids)
 
 
-def search_blocks(index, blocks, query_embeddings, topN):
-    """Resident multi-block search.  blocks: iterable of (emb, ids) in block order.
-    Returns (D float64 [nq, topN], I int64 [nq, topN])."""
+def _with_last_flag(it):
+    """(item, is_last) for every item of an iterator (one item of look-ahead)."""
+    it = iter(it)
+    try:
+        cur = next(it)
+    except StopIteration:
+        return
+    for nxt in it:
+        yield cur, False
+        cur = nxt
+    yield cur, True
+
+
+def _search_resident(index, q, dev, id_parts, sizes, last_ids, topN):
+    """One exact top-topN over the blocks now resident in `index` (rows in block order), ids remapped on the device,
+    the reference's padding of a degenerate corpus reproduced.  Resets the index (:122)."""
     import torch
-    dev = torch.device("cuda", index.devices[0])
-    index.reset()
-    id_parts, sizes, last_ids = [], [], []
-    for emb, ids in blocks:
-        index.add(emb)                                    # :98 (blocks stay resident; no reset between them)
-        ids = np.asarray(ids, dtype=np.int64)
-        id_parts.append(ids)
-        sizes.append(len(ids))
-        last_ids.append(int(ids[-1]) if len(ids) else -1)
-    q = np.ascontiguousarray(query_embeddings, dtype=np.float32)
-    nq = q.shape[0]
-    if not id_parts:
-        raise ValueError("no passage block could be loaded")  # the reference fails too (None has no len, :152)
     id_map = torch.from_numpy(np.concatenate(id_parts)).to(dev)
     if len(index.devices) == 1:
         D, I = index.search_tensor(torch.from_numpy(q).to(dev), topN, id_map=id_map)
@@ -68,10 +75,43 @@ def search_blocks(index, blocks, query_embeddings, topN):
     return D, I
 
 
-def search_one_by_one(args, passage_embeddings_dir, index, query_embeddings, topN):
-    """Drop-in for search_one_by_one_with_faiss(args, dir, index, Q, topN)."""
+def search_blocks(index, blocks, query_embeddings, topN, reference_shape=False):
+    """Resident multi-block search.  blocks: iterable of (emb, ids) in block order.
+    Returns (D float64 [nq, topN], I int64 [nq, topN]); with reference_shape=True and two or more blocks the
+    reference's literal (nq, 2*topN) matrices (module docstring)."""
+    import torch
+    dev = torch.device("cuda", index.devices[0])
+    q = np.ascontiguousarray(query_embeddings, dtype=np.float32)
+    index.reset()
+    id_parts, sizes, last_ids = [], [], []
+    head = None                                           # reference_shape: result over blocks 0..B-2
+    for (emb, ids), is_last in _with_last_flag(blocks):
+        if reference_shape and is_last and id_parts:
+            head = _search_resident(index, q, dev, id_parts, sizes, last_ids, topN)
+            id_parts, sizes, last_ids = [], [], []
+        index.add(emb)                                    # :98 (blocks stay resident; no reset between them)
+        ids = np.asarray(ids, dtype=np.int64)
+        id_parts.append(ids)
+        sizes.append(len(ids))
+        last_ids.append(int(ids[-1]) if len(ids) else -1)
+    if not id_parts:
+        raise ValueError("no passage block could be loaded")  # the reference fails too (None has no len, :152)
+    D, I = _search_resident(index, q, dev, id_parts, sizes, last_ids, topN)
+    if head is None:
+        return D, I
+    # :131-149 on (merged[:topN], cur[:topN]): a stable two-way merge, the running list first on equal scores (`>=`,
+    # :138), BOTH leftovers appended.  Both lists are sorted descending (pads, -FLT_MAX, last), so the merge is a stable
+    # sort of their concatenation by descending score.
+    cD, cI = np.concatenate([head[0], D], 1), np.concatenate([head[1], I], 1)
+    order = np.argsort(-cD, axis=1, kind="stable")
+    return np.take_along_axis(cD, order, 1), np.take_along_axis(cI, order, 1)
+
+
+def search_one_by_one(args, passage_embeddings_dir, index, query_embeddings, topN, reference_shape=False):
+    """Drop-in for search_one_by_one_with_faiss(args, dir, index, Q, topN).  reference_shape=True: the reference's
+    literal (nq, 2*topN) result when two or more blocks load (:144-162), see the module docstring."""
     blocks = iter_embedding_blocks(passage_embeddings_dir, args.passage_block_num)
-    merged_D, merged_I = search_blocks(index, blocks, query_embeddings, topN)
+    merged_D, merged_I = search_blocks(index, blocks, query_embeddings, topN, reference_shape=reference_shape)
     logger.info(merged_I.shape)
     return merged_D, merged_I
 

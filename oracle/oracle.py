@@ -98,14 +98,17 @@ class OracleIndex:
         self._rows = []
 
 
-def search_one_by_one(blocks, q, topN):
+def search_one_by_one(blocks, q, topN, reference_shape=False):
     """The reference's search_one_by_one_with_faiss (src/test_HAConvDR_qrecc.py:74-162) restated.
 
     blocks: iterable of (emb float32 [n_b,768], ids int64 [n_b]) in block order.
     Returns (merged_D float64 [nq, topN], merged_I int64 [nq, topN]) — the first
     topN columns of the reference's output, which is all its consumers read
-    (:238-239); the reference itself returns 2*topN columns when >=2 blocks load.
+    (:238-239); the reference itself returns 2*topN columns when >=2 blocks load:
+    reference_shape=True restates that literally (plain Python loops, small cases only).
     """
+    if reference_shape:
+        return _search_one_by_one_literal(blocks, q, topN)
     index = OracleIndex(q.shape[1])
     mD = mI = None
     for emb, ids in blocks:
@@ -125,6 +128,38 @@ def search_one_by_one(blocks, q, topN):
                                 _p(oI, ctypes.c_int64))
         mD, mI = oD, oI
     return mD, mI
+
+
+def _search_one_by_one_literal(blocks, q, topN):
+    """:74-162 line by line: lists of (score, passage) tuples, the two-pointer merge that stops consuming either
+    list at topN (:137-149) and therefore leaves 2*topN entries behind from the second block on."""
+    index = OracleIndex(q.shape[1])
+    merged = None
+    for emb, ids in blocks:
+        index.add(emb)                                   # :98
+        D, I = index.search(q, topN)                     # :102
+        cand_ids = np.asarray(ids)[I].tolist()           # :110
+        D = D.tolist()                                   # :111
+        cand = [list(zip(sl, pl)) for sl, pl in zip(D, cand_ids)]   # :115-120
+        index.reset()                                    # :122
+        if merged is None:                               # :126-128
+            merged = cand
+            continue
+        prev, merged = merged, []
+        for merged_list, cur_list in zip(prev, cand):    # :133-149
+            p1 = p2 = 0
+            out = []
+            while p1 < topN and p2 < topN:
+                if merged_list[p1][0] >= cur_list[p2][0]:
+                    out.append(merged_list[p1])
+                    p1 += 1
+                else:
+                    out.append(cur_list[p2])
+                    p2 += 1
+            out += merged_list[p1:topN] + cur_list[p2:topN]
+            merged.append(out)
+    return (np.array([[c[0] for c in row] for row in merged]),       # :151-159
+            np.array([[c[1] for c in row] for row in merged]))
 
 
 def num_threads():

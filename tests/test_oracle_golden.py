@@ -37,6 +37,16 @@ def test_oracle_matches_reference_merge(path, oracle):
     np.testing.assert_array_equal(mD, g["ref_D"][:, :topN])       # bit-exact scores
 
 
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[7:-4] for p in GOLD])
+def test_oracle_reference_shape_equals_the_reference_output_in_full(path, oracle):
+    """reference_shape=True: every column of the reference's (nq, 2*topN) matrices (test_HAConvDR_qrecc.py:144-162)."""
+    g, x, q, ids, blocks = load_case(path)
+    mD, mI = oracle.search_one_by_one(blocks, q, int(g["topN"]), reference_shape=True)
+    assert mD.shape == tuple(g["ref_shape"]) and mD.dtype == np.float64 and mI.dtype == np.int64
+    np.testing.assert_array_equal(mI, g["ref_I"])
+    np.testing.assert_array_equal(mD, g["ref_D"])
+
+
 def test_scalar_and_blocked_scores_agree(oracle):
     x, q, _ = cases.search_case_inputs("gauss", 77, 300, 11)
     s = oracle.ip_scores(x, q)

@@ -92,6 +92,11 @@ def test_search_one_by_one_dropin_vs_golden(path, index, tmp_path):
     assert mD.dtype == np.float64 and mI.dtype == np.int64 and mD.shape == (len(q), topN)
     np.testing.assert_array_equal(mI, g["ref_I"][:, :topN])
     np.testing.assert_array_equal(mD, g["ref_D"][:, :topN])
+    # the reference's literal result, (nq, 2 * topN) from the second block on (:144-162): every column
+    rD, rI = search_one_by_one(argparse.Namespace(passage_block_num=block_num), str(tmp_path), index, q, topN, reference_shape=True)
+    assert rD.shape == tuple(g["ref_shape"]) and rD.dtype == np.float64 and rI.dtype == np.int64
+    np.testing.assert_array_equal(rI, g["ref_I"])
+    np.testing.assert_array_equal(rD, g["ref_D"])
 
 
 @pytest.mark.parametrize("n,nq,k", [(1, 1, 1), (63, 3, 10), (64, 16, 64), (65, 17, 100), (1000, 33, 100),
