@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("HAC_LIBRARY_PATH") or os.path.join(_HERE, "csrc", "li
 _LIB = None
 
 HAC_MAX_K = 2048
+HAC_ERR_INTERNAL = 5   # include/haconvdr.h: the device detected a broken invariant of the library (never a hang, never wrong bits)
 
 
 class HacError(RuntimeError):
@@ -43,6 +44,8 @@ def _declare(L):
     L.hac_index_set_profiling.argtypes = [vp, ctypes.c_int]
     L.hac_index_profile_drain.argtypes = [vp, c_f32p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
     L.hac_index_last_plan.argtypes = [vp]
+    L.hac_index_last_status.argtypes = [vp]
+    L.hac_index_last_status.restype = ctypes.c_int
     L.hac_index_last_plan.restype = ctypes.c_char_p
     L.hac_merge_keys_device.argtypes = [ctypes.c_int, vp, ctypes.c_int, i64, ctypes.c_int, vp, vp]
     L.hac_keys_to_results_device.argtypes = [ctypes.c_int, vp, i64, vp, vp, vp, vp]
@@ -75,7 +78,7 @@ EXPORTED_SYMBOLS = (
     "hac_last_error", "hac_version", "hac_index_create", "hac_index_destroy", "hac_index_add",
     "hac_index_add_device", "hac_index_search", "hac_index_search_device", "hac_index_search_keys_device",
     "hac_index_reset", "hac_index_ntotal", "hac_index_set_option", "hac_index_set_profiling", "hac_index_profile_drain", "hac_index_last_plan",
-    "hac_merge_keys_device", "hac_keys_to_results_device",
+    "hac_index_last_status", "hac_merge_keys_device", "hac_keys_to_results_device",
     "hac_encoder_create", "hac_encoder_destroy", "hac_encoder_set_weight", "hac_encoder_finalize", "hac_encoder_forward",
     "hac_encoder_forward_device", "hac_encoder_set_option", "hac_encoder_last_plan", "hac_encoder_set_profiling", "hac_encoder_profile_drain",
     "hac_encoder_profile_drain_class",

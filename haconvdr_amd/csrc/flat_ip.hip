@@ -247,6 +247,27 @@ struct ScanArgs {
     // case: every workgroup exits at once).  Workgroups of dead query tiles join the live ones (vgrid).
     const int *nq_dev;
 };
+// Hang-proofing.  The candidate loops of scanq_kernel / scanh_kernel count the passes of a round that ended in an overflow
+// (in LDS, on the overflow route only) and give up at a bound no legal input reaches.  Nothing of this may cost the scan
+// kernels a register (scanh_kernel<1> sits at 256 VGPRs and spills SGPRs into them: one more kernel argument, or gridDim,
+// is a live SGPR pair from the first instruction on), so everything hangs off the chip-wide threshold array:
+//   thr_glob[-4]     debug pass bound (tests), 0 = the kernel's own           (the words in front are zeroed with the array)
+//   thr_glob[q]      = THR_POISON for the queries of a tile whose workgroup gave up.  As a threshold the value is inert (it
+//                    decodes to a NaN, which fmaxf ignores, and no score encodes to it: NaN scores never pass a threshold);
+//                    the survivors' flush keeps nothing for such a query and select_keys_kernel, which runs behind every
+//                    scan, returns an EMPTY list for it and sets the index's sticky error word (hac_index_last_status).
+constexpr u32 DEV_ERR_PASS_OVERRUN = 1u;
+constexpr u32 THR_POISON = 0xFFFFFFFFu;
+constexpr int THR_CTL_WORDS = 4;
+__device__ __forceinline__ u32 scan_pass_bound(const ScanArgs &a, u32 own) {
+    const u32 dbg = __hip_atomic_load(a.thr_glob - THR_CTL_WORDS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return dbg ? dbg : own;
+}
+// (workgroup-uniform call; the tile has at most as many queries as the workgroup has threads)
+__device__ __forceinline__ void scan_overrun(const ScanArgs &a, int q0, int nq_tile, int tid) {
+    asm volatile("" : "+v"(tid));   // the address is formed HERE: hoisted to the kernel's start it is a spilled register pair
+    if (tid < nq_tile) atomicMax(&a.thr_glob[q0 + tid], THR_POISON);
+}
 
 struct VGrid {
     u32 bx, by, nx;   // row stream, query tile, row streams per query tile: what blockIdx.x, blockIdx.y, gridDim.x are without nq_dev
@@ -502,7 +523,7 @@ __global__ __launch_bounds__(W * 64) void scanq_kernel(ScanArgs a) {
         // compacted: the overflow loop then never ends (found by a soak run; tests: stale fallback rows)
         thr[i] = i < NQr ? (a.thr_init ? a.thr_init[q0 + i] : -INFINITY) : __builtin_nanf("");
     }
-    if (tid == 0) *ovf = 0;
+    if (tid == 0) ovf[0] = ovf[1] = ovf[2] = 0;   // [0] overflow flag of the pass, [1] overflow passes of the round, [2] gave up
 #pragma unroll
     for (int i = 0; i < STG; ++i) qs[tid + i * NTHR] = qsrc[tid + i * NTHR];
     __syncthreads();
@@ -599,6 +620,11 @@ __global__ __launch_bounds__(W * 64) void scanq_kernel(ScanArgs a) {
                 }
             }
         }
+        // Every pass that leaves something pending has compacted the lists that were full, and a compacted list has room
+        // (C - max(hw, k) >= 1 slots): a query's W * 64 scores of a round are placed after at most W * 64 + 1 passes.  The
+        // bound is what turns a broken invariant (e.g. a threshold that admits a score its list can never take) into
+        // HAC_ERR_INTERNAL instead of a hang.
+        // The pass count lives in LDS (ovf[1]), counted by thread 0 on the overflow route only: the common round pays nothing.
         for (;;) {
             bool anyp = false;
 #pragma unroll
@@ -658,7 +684,12 @@ __global__ __launch_bounds__(W * 64) void scanq_kernel(ScanArgs a) {
             }
             __syncthreads();  // (A) compactions done, thresholds final
             if (!over) break;  // workgroup-uniform
-            if (tid == 0) *ovf = 0u;
+            if (tid == 0) {
+                *ovf = 0u;
+                const u32 np = ovf[1] + 1u;   // passes of this round that ended in an overflow
+                ovf[1] = np;
+                if (__builtin_expect(np >= scan_pass_bound(a, W * 64 + 4), 0)) ovf[2] = 1u;   // no legal input gets here
+            }
             // re-filter what is still pending against the raised thresholds, then offer it again
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
@@ -669,7 +700,13 @@ __global__ __launch_bounds__(W * 64) void scanq_kernel(ScanArgs a) {
                     if ((pend[n] & (1u << e)) && !(acc[n][e] >= th)) pend[n] &= ~(1u << e);
             }
             __syncthreads();  // flag reset ordered before the next pass's overflow stores
+            if (__builtin_expect(*(volatile u32 *)(ovf + 2) != 0u, 0)) {   // workgroup-uniform
+                static_assert(NQ <= NTHR, "one thread per query of the tile");
+                scan_overrun(a, q0, NQr, tid);   // poisoned tile, on with the next round
+                break;
+            }
         }
+        if (tid == 0) ovf[1] = ovf[2] = 0u;   // (read again only behind the barriers of a later overflow pass)
         item = nitem;
         have = have_next;
     }
@@ -934,6 +971,7 @@ struct DeviceIndex {
         bool no_p8 = false;
         int seed_groups_max = 0;         // cap of the seeding pass of the prefilter scan, in 64-row groups; 0 = 14 sqrt(groups)
         int split_decide = -1;           // who reads the certificates: -1 by entry point (host API: host, *_device: device), 0 host, 1 device
+        int debug_max_pass = 0;          // tests: pass bound of the candidate loops (0 = the kernels' own, which no legal input reaches)
     } tune;
     void read_env() {
         if (const char *e = getenv("HAC_SPLIT")) tune.split = e[0] == '0' ? 0 : (e[0] == '1' ? 1 : -1);
@@ -976,6 +1014,11 @@ struct DeviceIndex {
         } else if (n == "split_decide") {
             if (!one_of({"auto", "host", "device"})) return HAC_ERR_INVALID;
             tune.split_decide = v == "host" ? 0 : (v == "device" ? 1 : -1);
+        } else if (n == "debug_max_pass") {
+            char *end = nullptr;
+            const long t = strtol(v.c_str(), &end, 10);
+            if (v.empty() || *end || t < 0 || t > 1000000) return fail(HAC_ERR_INVALID, "index option debug_max_pass = '%s': an integer >= 0", v.c_str());
+            tune.debug_max_pass = (int)t;
         } else if (n == "seed_groups_max") {
             char *end = nullptr;
             const long t = strtol(v.c_str(), &end, 10);
@@ -989,6 +1032,9 @@ struct DeviceIndex {
     GrowBuf ws_partial, ws_pcnt, ws_seedkeys, ws_thr, ws_thrglob, ws_q, ws_qt, ws_keys, ws_D, ws_I, ws_stage[2];
     // split-bf16 prefilter path (scan_split.inc)
     GrowBuf ws_norm, ws_qsplit, ws_delta, ws_cand, ws_akeys, ws_fail, ws_stat;
+    GrowBuf ws_err;            // [0] device error bits (sticky until read), [1] workgroups that hit a pass bound (ScanArgs::err)
+    u32 *h_err = nullptr;      // pinned copy
+
     GrowBuf ws_fbidx[2], ws_fbq[2], ws_fbkeys[2];   // per cascade level: failed queries, their matrix, their keys
     u32 *h_fb = nullptr;       // pinned: [0] failed queries, [1] max |s~ - s| / delta (float bits), [2..] flags / indices
     size_t h_fb_words = 0;
@@ -1035,6 +1081,9 @@ struct DeviceIndex {
         for (int i = 0; i < 2; ++i) HAC_HIP(hipEventCreateWithFlags(&stage_ev[i], hipEventDisableTiming));
         HAC_TRY(ws_norm.reserve(16));
         HAC_HIP(hipMemsetAsync(ws_norm.p, 0, 16, stream));
+        HAC_TRY(ws_err.reserve(16));   // (a new GrowBuf is zero)
+        HAC_HIP(hipHostMalloc((void **)&h_err, 16, hipHostMallocDefault));
+        h_err[0] = h_err[1] = 0u;
         static bool attr_done[64] = {false};
         if (device < 64 && !attr_done[device]) {
             HAC_HIP(hipFuncSetAttribute((const void *)scan16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1066,10 +1115,11 @@ struct DeviceIndex {
         if (h_segs) (void)hipHostFree(h_segs);
         if (h_pin) (void)hipHostFree(h_pin);
         for (GrowBuf *b : {&ws_partial, &ws_pcnt, &ws_seedkeys, &ws_thr, &ws_thrglob, &ws_q, &ws_qt, &ws_keys, &ws_D, &ws_I, &ws_stage[0],
-                           &ws_stage[1], &ws_norm, &ws_qsplit, &ws_delta, &ws_cand, &ws_akeys, &ws_fail, &ws_stat, &ws_fbidx[0], &ws_fbidx[1],
+                           &ws_stage[1], &ws_err, &ws_norm, &ws_qsplit, &ws_delta, &ws_cand, &ws_akeys, &ws_fail, &ws_stat, &ws_fbidx[0], &ws_fbidx[1],
                            &ws_fbq[0], &ws_fbq[1], &ws_fbkeys[0], &ws_fbkeys[1]})
             b->release();
         if (h_fb) (void)hipHostFree(h_fb);
+        if (h_err) (void)hipHostFree(h_err);
         for (int i = 0; i < 2; ++i) {
             if (h_stage[i]) (void)hipHostFree(h_stage[i]);
             if (stage_ev[i]) (void)hipEventDestroy(stage_ev[i]);
@@ -1111,8 +1161,34 @@ struct DeviceIndex {
         ntotal = 0;
         segs_dirty = true;
         HAC_HIP(hipMemsetAsync(ws_norm.p, 0, 16, stream));
+        HAC_HIP(hipMemsetAsync(ws_err.p, 0, 16, stream));
         HAC_HIP(hipStreamSynchronize(stream));
         return HAC_OK;
+    }
+
+    // the chip-wide thresholds of the next scan launch and the control words in front of them (see scan_pass_bound)
+    int clear_thrglob(size_t nq_pad, hipStream_t st) {
+        HAC_HIP(hipMemsetAsync(ws_thrglob.p, 0, (nq_pad + THR_CTL_WORDS) * 4, st));
+        if (tune.debug_max_pass > 0) HAC_HIP(hipMemsetD32Async((hipDeviceptr_t)ws_thrglob.p, tune.debug_max_pass, 1, st));
+        return HAC_OK;
+    }
+    u32 *thrglob() const { return (u32 *)ws_thrglob.p + THR_CTL_WORDS; }
+
+    // The device's error word, as of everything that has completed on `st` (enqueue + wait): HAC_ERR_INTERNAL if a scan
+    // workgroup hit its pass bound since the word was last read; reading clears it.
+    int fetch_err(hipStream_t st) {
+        HAC_HIP(hipMemcpyAsync(h_err, ws_err.p, 8, hipMemcpyDeviceToHost, st));
+        HAC_HIP(hipStreamSynchronize(st));
+        return check_err(st);
+    }
+    // h_err already copied and the stream synchronized by the caller
+    int check_err(hipStream_t st) {
+        if (h_err[0] == 0u) return HAC_OK;
+        const u32 bits = h_err[0], n = h_err[1];
+        h_err[0] = h_err[1] = 0u;
+        HAC_HIP(hipMemsetAsync(ws_err.p, 0, 16, st));
+        return fail(HAC_ERR_INTERNAL, "device %d: %u scan workgroup(s) reached the pass bound of their candidate loop (error bits 0x%x): a broken "
+                    "invariant of the library, not of the input; the queries of those tiles were returned with EMPTY lists", device, n, bits);
     }
 
     // make room for m more rows: returns (segment index) whose rows..cap_rows can take them in pieces
@@ -1382,12 +1458,12 @@ struct DeviceIndex {
         a.g_step = g_step;
         a.n_items = n_items;
         a.thr_init = thr_init;
-        a.thr_glob = (u32 *)ws_thrglob.p;
+        a.thr_glob = thrglob();
         a.partial = (u64 *)ws_partial.p;
         a.partial_cnt = (u32 *)ws_pcnt.p;
         HAC_HIP(hipMemsetAsync(ws_pcnt.p, 0, (size_t)nq * 4, st));
         a.pos_base = pos_base;
-        HAC_HIP(hipMemsetAsync(ws_thrglob.p, 0, (size_t)pl.n_qtiles * pl.QT * 4, st));
+        HAC_TRY(clear_thrglob((size_t)pl.n_qtiles * pl.QT, st));
         if (timed) {
             if (ev_used == ev_pool.size()) {
                 hipEvent_t a0, a1;
@@ -1440,7 +1516,7 @@ struct DeviceIndex {
         // device-side count: a live tile may own every workgroup of the grid; QT * (P * n_qtiles) * k keys bound any split
         HAC_TRY(ws_partial.reserve(nq_dev ? (size_t)pl.QT * pl.P * pl.n_qtiles * k * 8 : (size_t)nq * pl.P * k * 8));
         HAC_TRY(ws_pcnt.reserve((size_t)nq * 4));
-        HAC_TRY(ws_thrglob.reserve((size_t)pl.n_qtiles * pl.QT * 4));
+        HAC_TRY(ws_thrglob.reserve(((size_t)pl.n_qtiles * pl.QT + THR_CTL_WORDS) * 4));
         if (pl.kind == 1) {
             const long total = (long)pl.n_qtiles * K4 * pl.QT;
             HAC_TRY(ws_qt.reserve((size_t)total * 16));
@@ -1490,7 +1566,7 @@ struct DeviceIndex {
         select_keys_kernel<<<dim3((unsigned)nq), dim3(256), (size_t)np2 * 8, st>>>((const u64 *)ws_partial.p, (size_t)pl.P * k,
                                                                                    (const u32 *)ws_pcnt.p, (u32)((size_t)pl.P * k), k, np2,
                                                                                    keys_out, nullptr, nq_dev, (int)nq, (u32)(pl.P * pl.n_qtiles),
-                                                                                   (u32)pl.QT);
+                                                                                   (u32)pl.QT, thrglob(), (u32 *)ws_err.p);
         HAC_HIP(hipGetLastError());
         return HAC_OK;
     }
@@ -1541,7 +1617,7 @@ struct DeviceIndex {
         HAC_TRY(ws_cand.reserve((size_t)Pmax * SH_NQ * C2 * 8));          // P * n_qtiles <= n_cu workgroups
         HAC_TRY(ws_partial.reserve((size_t)chunk * Pmax * K2 * 8));
         HAC_TRY(ws_pcnt.reserve((size_t)chunk * 4));
-        HAC_TRY(ws_thrglob.reserve((size_t)n_qtiles_max * SH_NQ * 4));
+        HAC_TRY(ws_thrglob.reserve(((size_t)n_qtiles_max * SH_NQ + THR_CTL_WORDS) * 4));
         HAC_TRY(ws_akeys.reserve((size_t)nq * K2 * 8));
         HAC_TRY(ws_fail.reserve((size_t)nq * 4));
         HAC_TRY(ws_stat.reserve(16));
@@ -1558,7 +1634,7 @@ struct DeviceIndex {
         a.k = K2;
         a.g_first = 0;
         a.g_step = 1;
-        a.thr_glob = (u32 *)ws_thrglob.p;
+        a.thr_glob = thrglob();
         a.partial = (u64 *)ws_partial.p;
         a.partial_cnt = (u32 *)ws_pcnt.p;
         SplitArgs sp{};
@@ -1588,7 +1664,7 @@ struct DeviceIndex {
             sp.delta = delta_c;
             sp.pstride = pstride;
             HAC_HIP(hipMemsetAsync(ws_pcnt.p, 0, (size_t)n * 4, st));
-            HAC_HIP(hipMemsetAsync(ws_thrglob.p, 0, (size_t)nq_pad * 4, st));
+            HAC_TRY(clear_thrglob((size_t)nq_pad, st));
             if (profiling) {
                 if (ev_used == ev_pool.size()) {
                     hipEvent_t a0, a1;
@@ -1633,7 +1709,8 @@ struct DeviceIndex {
             }
             // exact top-K2 by approximate score over all workgroups' survivors
             select_keys_kernel<<<dim3((unsigned)n), dim3(256), (size_t)K2 * 8, st>>>((const u64 *)ws_partial.p, (size_t)pstride,
-                                                                                     (const u32 *)ws_pcnt.p, (u32)pstride, K2, K2, akeys_c, nullptr);
+                                                                                     (const u32 *)ws_pcnt.p, (u32)pstride, K2, K2, akeys_c, nullptr,
+                                                                                     nullptr, 0, 0, 1, thrglob(), (u32 *)ws_err.p);
             HAC_HIP(hipGetLastError());
             // rescoring + certificate of this chunk on the second stream (reads only akeys, delta, the queries and
             // the corpus; everything the next chunk's scan reuses is already consumed)
@@ -1982,6 +2059,7 @@ int hac_index_search(hac_index *idx, const float *q, int64_t nq, int k, float *D
         std::memcpy(s->h_pin, q, qbytes);
         HAC_HIP(hipMemcpyAsync(s->ws_q.p, s->h_pin, qbytes, hipMemcpyHostToDevice, s->stream));
         HAC_TRY(s->search_keys((const float *)s->ws_q.p, nq, k, (u64 *)s->ws_keys.p, 0u, s->stream));
+        HAC_HIP(hipMemcpyAsync(s->h_err, s->ws_err.p, 8, hipMemcpyDeviceToHost, s->stream));   // checked after the final wait
         if (S > 1) {   // shard-local rows -> insertion-order positions of the whole index
             const std::vector<SpanDesc> &sp = idx->spans[si];
             if (!sp.empty()) {
@@ -2039,6 +2117,21 @@ int hac_index_search(hac_index *idx, const float *q, int64_t nq, int k, float *D
     HAC_HIP(hipStreamSynchronize(s0->stream));
     std::memcpy(I, hp, (size_t)nq * k * 8);
     std::memcpy(D, hp + (size_t)nq * k * 8, (size_t)nq * k * 4);
+    // a scan workgroup that ran into its pass bound: the results are delivered (the affected lists EMPTY), the call says so
+    for (auto *s : idx->shards) {
+        DeviceGuard gs(s->device);
+        HAC_TRY(s->check_err(s->stream));
+    }
+    return HAC_OK;
+}
+
+int hac_index_last_status(hac_index *idx) {
+    if (!idx) return fail(HAC_ERR_INVALID, "null index");
+    for (auto *s : idx->shards) {
+        DeviceGuard g(s->device);
+        if (!g.ok) return fail(HAC_ERR_HIP, "cannot select HIP device %d", s->device);
+        HAC_TRY(s->fetch_err(s->stream));
+    }
     return HAC_OK;
 }
 

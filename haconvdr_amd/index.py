@@ -131,6 +131,12 @@ class FlatIPIndex:
     def last_plan(self):
         return _lib.lib().hac_index_last_plan(self._h).decode()
 
+    def check_status(self):
+        """Raise HacError (code HAC_ERR_INTERNAL) if a scan of a search enqueued so far gave up at its pass bound
+        (hac_index_last_status).  The host API reports this itself; after ``search_tensor`` / ``search_keys_tensor``
+        synchronize the stream you searched on, then call this.  Reading clears the error word."""
+        _lib.check(_lib.lib().hac_index_last_status(self._h))
+
     def profile_drain(self, cap=4096):
         """Durations (ms) of the main scan kernel of every search since the last drain."""
         buf = (ctypes.c_float * cap)()

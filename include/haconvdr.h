@@ -43,7 +43,10 @@ typedef enum {
     HAC_ERR_INVALID = 1,   /* bad argument (null handle, d not a multiple of 32, k out of range, ...) */
     HAC_ERR_HIP = 2,       /* a HIP runtime call failed / no device */
     HAC_ERR_OOM = 3,       /* device or pinned-host allocation failed */
-    HAC_ERR_UNSUPPORTED = 4
+    HAC_ERR_UNSUPPORTED = 4,
+    HAC_ERR_INTERNAL = 5   /* the device detected a broken invariant of the library itself (a candidate loop ran past the pass
+                              count no legal input reaches): the affected queries' lists are returned EMPTY (-FLT_MAX / -1), never
+                              wrong, and the call (host entry points) or hac_index_last_status (after *_device calls) says so */
 } hac_status;
 
 #define HAC_MAX_K 2048      /* faiss-gpu 1.7.2 has the same top-k ceiling */
@@ -113,11 +116,19 @@ int hac_index_search_keys_device(hac_index *idx, const float *q_dev, int64_t nq,
 int hac_index_reset(hac_index *idx);
 /* index.ntotal */
 int64_t hac_index_ntotal(const hac_index *idx);
+/* Device-detected failures of searches enqueued so far (the host entry points report them themselves; the *_device entry
+ * points cannot, they never read back).  Waits for the index's own streams only: synchronize YOUR stream first, then call
+ * this.  Returns HAC_OK, or HAC_ERR_INTERNAL with the details in hac_last_error(); reading clears the device's error word
+ * (hac_index_reset clears it too).  Every scan kernel bounds its candidate-compaction loop by the number of passes the
+ * worst legal input needs; a workgroup that reaches the bound sets the word, drops what it still held, and the queries of
+ * its tile come back with EMPTY lists: an invariant slip is an error code, not a hang and not wrong bits. */
+int hac_index_last_status(hac_index *idx);
 
 /* Tuning and test switches of a live handle: "split" = "0" | "1" | "auto", "split_terms" = "1" | "3",
  * "force_scan16" = "0" | "1", "scanq_nt" = "0".."4", "scanq_waves" = "4" | "8", "scan_no_p8" = "0" | "1",
  * "seed_groups_max" = cap of the prefilter's seeding pass in 64-row groups (integer >= 0; 0 = 14 sqrt(groups)),
- * "split_decide" = "auto" (host entry point: host, *_device: device) | "host" | "device": who reads the certificates.
+ * "split_decide" = "auto" (host entry point: host, *_device: device) | "host" | "device": who reads the certificates,
+ * "debug_max_pass" = integer >= 0 (tests: the pass bound of the candidate loops; 0 = the bound no legal input reaches).
  * Any other name or value is HAC_ERR_INVALID (never a silent default).
  * The HAC_<NAME> environment variables give the defaults and are read once, in hac_index_create. */
 int hac_index_set_option(hac_index *idx, const char *name, const char *value);

@@ -986,3 +986,83 @@ def test_device_decided_fallback_ignores_stale_rows_behind_the_count(oracle):
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "fallback=1/130" in r.stdout, r.stdout   # the case really takes the fallback with one live query
+
+
+@pytest.mark.gpu
+def test_pass_bound_turns_a_runaway_candidate_loop_into_an_error():
+    """Hang-proofing.  The candidate loops of scanq_kernel / scanh_kernel are bounded by a pass count no
+    legal input reaches; past it the workgroup poisons its tile's queries (EMPTY lists), the index's error word is set, the
+    host entry point returns HAC_ERR_INTERNAL and hac_index_last_status reports it after a *_device call.  The debug option
+    `debug_max_pass` lowers the bound so that legal (adversarial: every row beats all rows before it) data overruns it.  Run in
+    a child process under a time limit: the failure mode this guards against is a kernel that never ends."""
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np, torch
+        sys.path.insert(0, %r)
+        from haconvdr_amd import _lib
+        from haconvdr_amd.index import FlatIPIndex
+        from oracle import oracle
+        FMAX = np.finfo(np.float32).max
+
+        def expect_internal(fn):
+            try:
+                fn()
+            except _lib.HacError as e:
+                assert e.code == _lib.HAC_ERR_INTERNAL, e
+                assert "pass bound" in str(e), e
+                return
+            raise AssertionError("no HAC_ERR_INTERNAL")
+
+        # ---- exact fp32 kernels (scanq_kernel): 512 passing rows per query and round against 32 list slots
+        n, nq, k = 6000, 40, 10
+        x = np.zeros((n, 768), np.float32); x[:, 0] = (np.arange(n, dtype=np.float32) + 1.0) / 64.0
+        q = np.zeros((nq, 768), np.float32); q[:, 0] = 1.0 + np.arange(nq, dtype=np.float32) / 8.0
+        oD, oI = oracle.flat_ip_search(x, q, k)
+        idx = FlatIPIndex(768); idx.add(x)
+        D, I = idx.search(q, k); assert np.array_equal(I, oI) and np.array_equal(D, oD)
+        idx.check_status()                                            # nothing to report
+        idx.set_option("debug_max_pass", "2")
+        expect_internal(lambda: idx.search(q, k))                     # host entry point: the call itself says so
+        idx.check_status()                                            # ... and reading cleared the word
+        qt = torch.from_numpy(q).cuda()
+        Dt, It = idx.search_tensor(qt, k); torch.cuda.synchronize()   # device entry point: results delivered, never wrong
+        Dt, It = Dt.cpu().numpy(), It.cpu().numpy()
+        empty = (It == -1).all(1)
+        assert empty.any(), "the lowered bound was not reached"
+        assert (Dt[empty] == -FMAX).all()
+        assert np.array_equal(It[~empty], oI[~empty]) and np.array_equal(Dt[~empty], oD[~empty])
+        expect_internal(idx.check_status)
+        idx.check_status()
+        idx.set_option("debug_max_pass", "0")
+        D, I = idx.search(q, k); assert np.array_equal(I, oI) and np.array_equal(D, oD)   # the handle is fine afterwards
+        print("SCANQ", idx.last_plan())
+
+        # ---- prefilter (scanh_kernel): 192 of a round's 256 rows pass, lists of 512 with compaction past 384: 0 -> 192 -> 384 -> 576
+        n, nq, k = 131072, 1024, 100
+        x0 = (np.arange(n, dtype=np.float32) + 1.0) / 64.0
+        x0[np.arange(n) %% 4 == 3] = -1000.0
+        x = np.zeros((n, 768), np.float32); x[:, 0] = x0
+        q = np.zeros((nq, 768), np.float32); q[:, 0] = 1.0 + (np.arange(nq, dtype=np.float32) %% 64) / 8.0
+        sel = [0, 1, 63, 64, 500, 1023]
+        oD, oI = oracle.flat_ip_search(x, q[sel], k)
+        idx = FlatIPIndex(768); idx.set_option("split", "1"); idx.add(x)
+        idx.set_option("debug_max_pass", "1")
+        expect_internal(lambda: idx.search(q, k))
+        assert idx.last_plan().startswith("split:"), idx.last_plan()
+        qt = torch.from_numpy(q).cuda()
+        Dt, It = idx.search_tensor(qt, k); torch.cuda.synchronize()
+        Dt, It = Dt.cpu().numpy()[sel], It.cpu().numpy()[sel]
+        empty = (It == -1).all(1)
+        assert np.array_equal(It[~empty], oI[~empty]) and np.array_equal(Dt[~empty], oD[~empty])
+        expect_internal(idx.check_status)
+        idx.set_option("debug_max_pass", "0")
+        D, I = idx.search(q, k); assert np.array_equal(I[sel], oI) and np.array_equal(D[sel], oD)
+        Dt, It = idx.search_tensor(qt, k); torch.cuda.synchronize(); idx.check_status()
+        assert np.array_equal(It.cpu().numpy()[sel], oI) and np.array_equal(Dt.cpu().numpy()[sel], oD)
+        print("SCANH", idx.last_plan())
+    """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "SCANQ" in r.stdout and "SCANH" in r.stdout, r.stdout

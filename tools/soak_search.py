@@ -49,6 +49,7 @@ while time.time() - t0 < budget:
         for split in ("1", "0"):
             D, I = idxs[split].search_tensor(qr, k)
             torch.cuda.synchronize()
+            idxs[split].check_status()   # a scan that gave up at its pass bound is HAC_ERR_INTERNAL here, not a hang
             res.append((D.clone(), I.clone(), idxs[split].last_plan()))
         # NaN scores compare unequal: ids are what is compared there
         same = torch.equal(res[0][1], res[1][1]) and torch.equal(torch.nan_to_num(res[0][0], nan=0.0), torch.nan_to_num(res[1][0], nan=0.0))
