@@ -1312,7 +1312,22 @@ struct hac_encoder {
     const char *plan_gemm = "none";
     int plan_sub_batches = 0;
     long plan_rows = 0;
+    const char *plan_graph = "off";
     char last_plan[160] = "none";
+    // Small batches (the reference's own call shape is 4 queries per GPU, test_HAConvDR_topiocqa.py:173,406) are bound by
+    // launches, not arithmetic: ~110 kernels for ~0.4 TFLOP.  Their forward is captured ONCE per (B, L, options) into a HIP
+    // graph over private input / output buffers and replayed: one graph launch + three small copies per call.
+    int graph_mode = -1;                  // -1: small batches without profiling, 0: never
+    struct GraphEntry {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        uint64_t sig = 0;                 // digest of every workspace pointer the captured launches hold
+        int seen = 0;                     // eager passes so far (the first call sizes the workspaces)
+        const char *gemm = "none";
+        long rows = 0;
+    };
+    std::map<uint64_t, GraphEntry> graphs;
+    GrowBuf ws_gids, ws_gmask, ws_gout;
 };
 
 namespace {
@@ -1372,9 +1387,17 @@ int seq_layout(hac_encoder *e, int B, int L, SeqInfo &s) {
 
 // rows_hint: an upper bound of the packed rows of this sub-batch when the caller knows one (sum of its
 // sequences' padded lengths), 0 = every sequence may be full length
-// g8_call: the GEMM family of the whole hac_encoder_forward* call (-1: decide here, from this sub-batch's rows)
+// family: the GEMM family of the whole hac_encoder_forward* call -- FAM_CLASSIC128 / FAM_CLASSIC256 / FAM_GEMM8 -- or -1:
+// decide here, from this (only) sub-batch's rows
+enum { FAM_CLASSIC128 = 0, FAM_GEMM8 = 1, FAM_CLASSIC256 = 2 };
+int pick_family(const hac_encoder *e, long rows) {
+    const long Mp = (rows + MT - 1) / MT * MT;
+    const bool big = (Mp / 256) * (H / 256) >= 128;   // 256^2 tiles once they fill the chip
+    if (e->gemm_mode == 1 || (e->gemm_mode < 0 && big)) return FAM_GEMM8;
+    return big ? FAM_CLASSIC256 : FAM_CLASSIC128;
+}
 template <typename IT>
-int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, float *out_dev, hipStream_t st, long rows_hint = 0, int g8_call = -1) {
+int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, float *out_dev, hipStream_t st, long rows_hint = 0, int family = -1) {
     const hac_encoder_config &c = e->cfg;
     const int L32 = (L + SEQ_ALIGN - 1) / SEQ_ALIGN * SEQ_ALIGN;
     const long rows_max = rows_hint > 0 ? std::min<long>(rows_hint, (long)B * L32) : (long)B * L32;
@@ -1397,12 +1420,14 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
     float2 *statsA = (float2 *)e->ws_stats.p, *statsF = statsA + Mp;
     bf16 *xb = (bf16 *)e->ws_xb.p, *q = (bf16 *)e->ws_q.p, *k = (bf16 *)e->ws_k.p, *vt = (bf16 *)e->ws_vt.p;
     bf16 *ctx = (bf16 *)e->ws_ctx.p, *h = (bf16 *)e->ws_h.p;
-    // tile choice: 256^2 tiles once they fill the chip, 128^2 tiles for small batches; persistent grids
-    const bool big = (Mp / 256) * (H / 256) >= 128;
-    // large batches: the ping-pong GEMM with the LayerNorms folded into the consuming weights (gemm8.inc).  The family is
-    // chosen ONCE per hac_encoder_forward* call, from the whole batch (forward_batched): a small tail sub-batch of a large
-    // forward runs the same kernels as the others, so a sequence's embedding does not depend on which sub-batch it fell into.
-    const bool g8 = g8_call >= 0 ? g8_call != 0 : (e->gemm_mode == 1 || (e->gemm_mode < 0 && big));
+    // tile choice: 256^2 tiles once they fill the chip, 128^2 tiles for small batches; persistent grids.
+    // Large batches: the ping-pong GEMM with the LayerNorms folded into the consuming weights (gemm8.inc).  The family -- and
+    // with the classic kernels the tile -- is chosen ONCE per hac_encoder_forward* call, from the whole batch
+    // (forward_batched): a small tail sub-batch of a large forward runs the same kernels as the others, so a sequence's
+    // embedding does not depend on which sub-batch it fell into.
+    if (family < 0) family = pick_family(e, rows_max);
+    const bool g8 = family == FAM_GEMM8;
+    const bool big = family == FAM_CLASSIC256 || (g8 && (Mp / 256) * (H / 256) >= 128);
     // (that path's residual stream is bf16 from the embedding rows on: no fp32 copy of them, 3 KB per token less to write)
     embed_ln_kernel<IT><<<dim3(L32 / 4, B), dim3(256), 0, st>>>(ids, L, s, e->word, e->posw, e->typew, e->embg, e->embb, c.ln_eps, c.vocab, g8 ? nullptr : x, xb);
     HAC_HIP(hipGetLastError());
@@ -1569,11 +1594,90 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
     return HAC_OK;
 }
 
+// ---- small batches: capture once, replay (see hac_encoder::graph_mode)
+constexpr long GRAPH_MAX_ROWS = 16384;   // beyond this a forward is milliseconds of kernels: launches no longer matter
+uint64_t ws_signature(const hac_encoder *e) {
+    uint64_t h = 1469598103934665603ull;
+    for (const GrowBuf *b : {&e->ws_x, &e->ws_xb, &e->ws_q, &e->ws_k, &e->ws_vt, &e->ws_ctx, &e->ws_y, &e->ws_h, &e->ws_seq, &e->ws_cls, &e->ws_stats,
+                             &e->ws_yb, &e->ws_part, &e->ws_idstats, &e->ws_gids, &e->ws_gmask, &e->ws_gout})
+        h = (h ^ (uint64_t)(uintptr_t)b->p) * 1099511628211ull;
+    return h;
+}
+void drop_graphs(hac_encoder *e) {
+    for (auto &kv : e->graphs) {
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+    }
+    e->graphs.clear();
+}
+bool graph_eligible(const hac_encoder *e, int B, int L, hipStream_t st) {
+    if (e->graph_mode == 0 || e->prof_mask != 0) return false;
+    const int L32 = (L + SEQ_ALIGN - 1) / SEQ_ALIGN * SEQ_ALIGN;
+    if ((long)B * L32 > GRAPH_MAX_ROWS) return false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;   // the caller captures: plain launches
+    return true;
+}
+template <typename IT>
+int forward_graph(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, float *out_dev, hipStream_t st) {
+    const size_t n_in = (size_t)B * L * sizeof(IT), n_out = (size_t)B * H * 4;
+    HAC_TRY(e->ws_gids.reserve(n_in));
+    HAC_TRY(e->ws_gmask.reserve(n_in));
+    HAC_TRY(e->ws_gout.reserve(n_out));
+    const uint64_t key = ((uint64_t)B << 40) | ((uint64_t)L << 24) | ((uint64_t)sizeof(IT) << 16) | ((uint64_t)(e->attn_mode & 1) << 8) |
+                         ((uint64_t)((e->gemm_mode + 1) & 3) << 4) | (uint64_t)(e->g8_split & 15);
+    hac_encoder::GraphEntry &ge = e->graphs[key];
+    const IT *gids = (const IT *)e->ws_gids.p, *gmask = (const IT *)e->ws_gmask.p;
+    float *gout = (float *)e->ws_gout.p;
+    HAC_HIP(hipMemcpyAsync(e->ws_gids.p, ids, n_in, hipMemcpyDeviceToDevice, st));
+    HAC_HIP(hipMemcpyAsync(e->ws_gmask.p, mask, n_in, hipMemcpyDeviceToDevice, st));
+    e->plan_sub_batches = 1;
+    if (ge.seen == 0) {
+        // first call of this shape: plain launches through the private buffers -- sizes every workspace (no allocation may
+        // happen inside a capture) and is a valid forward by itself
+        e->plan_rows = 0;
+        HAC_TRY(run_forward<IT>(e, gids, gmask, B, L, gout, st));
+        ge.seen = 1;
+        ge.gemm = e->plan_gemm;
+        ge.rows = e->plan_rows;
+        e->plan_sub_batches = 1;
+        e->plan_graph = "eager-first";
+    } else {
+        if (!ge.exec || ge.sig != ws_signature(e)) {
+            // (a larger forward in between may have regrown a workspace: the captured launches hold the old pointers)
+            if (ge.exec) (void)hipGraphExecDestroy(ge.exec);
+            if (ge.graph) (void)hipGraphDestroy(ge.graph);
+            ge.exec = nullptr;
+            ge.graph = nullptr;
+            HAC_HIP(hipStreamSynchronize(e->stream));
+            HAC_HIP(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+            e->plan_rows = 0;
+            const int rc = run_forward<IT>(e, gids, gmask, B, L, gout, e->stream);
+            const hipError_t ce = hipStreamEndCapture(e->stream, &ge.graph);
+            e->plan_sub_batches = 1;
+            if (rc != HAC_OK) return rc;
+            if (ce != hipSuccess || !ge.graph) return fail(HAC_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+            HAC_HIP(hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));
+            ge.sig = ws_signature(e);
+            ge.gemm = e->plan_gemm;
+            ge.rows = e->plan_rows;
+        }
+        HAC_HIP(hipGraphLaunch(ge.exec, st));
+        e->plan_gemm = ge.gemm;
+        e->plan_rows = ge.rows;
+        e->plan_graph = "replay";
+    }
+    HAC_HIP(hipMemcpyAsync(out_dev, gout, n_out, hipMemcpyDeviceToDevice, st));
+    return HAC_OK;
+}
+
 template <typename IT>
 int forward_batched(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, float *out_dev, hipStream_t st) {
     const int L32 = (L + SEQ_ALIGN - 1) / SEQ_ALIGN * SEQ_ALIGN;
     e->plan_sub_batches = 0;
     e->plan_rows = 0;
+    e->plan_graph = "off";
+    if (graph_eligible(e, B, L, st)) return forward_graph<IT>(e, ids, mask, B, L, out_dev, st);
     if ((long)B * L32 <= e->max_tokens) return run_forward<IT>(e, ids, mask, B, L, out_dev, st);
     // More rows than one pass holds if every sequence were full length: size the sub-batches by the REAL padded
     // lengths (one seq_prep over the whole batch and a B-int read-back), so that varlen batches fill the
@@ -1598,7 +1702,7 @@ int forward_batched(hac_encoder *e, const IT *ids, const IT *mask, int B, int L,
     long rows_all = 0;
     for (int b = 0; b < B; ++b) rows_all += std::min<long>(std::max(len32[b], SEQ_ALIGN), L32);
     const long rows_first = std::min<long>(rows_all, e->max_tokens);
-    const int g8_call = (e->gemm_mode == 1 || (e->gemm_mode < 0 && ((rows_first + MT - 1) / MT) * (H / 256) >= 128)) ? 1 : 0;
+    const int family = pick_family(e, rows_first);   // GEMM family AND classic tile size: one choice for every sub-batch of the call
     for (int b0 = 0; b0 < B;) {
         long rows = 0;
         int nb = 0;
@@ -1608,7 +1712,7 @@ int forward_batched(hac_encoder *e, const IT *ids, const IT *mask, int B, int L,
             rows += r;
             ++nb;
         }
-        HAC_TRY(run_forward<IT>(e, ids + (size_t)b0 * L, mask + (size_t)b0 * L, nb, L, out_dev + (size_t)b0 * H, st, rows, g8_call));
+        HAC_TRY(run_forward<IT>(e, ids + (size_t)b0 * L, mask + (size_t)b0 * L, nb, L, out_dev + (size_t)b0 * H, st, rows, family));
         b0 += nb;
     }
     return HAC_OK;
@@ -1684,7 +1788,9 @@ void hac_encoder_destroy(hac_encoder *e) {
         if (l.w18) (void)hipFree(l.w18);
         if (l.fold) (void)hipFree(l.fold);
     }
-    for (GrowBuf *b : {&e->ws_x, &e->ws_xb, &e->ws_q, &e->ws_k, &e->ws_vt, &e->ws_ctx, &e->ws_y, &e->ws_h, &e->ws_seq, &e->ws_ids, &e->ws_mask, &e->ws_out, &e->ws_cls, &e->ws_stats, &e->ws_yb, &e->ws_part, &e->ws_idstats})
+    drop_graphs(e);
+    for (GrowBuf *b : {&e->ws_x, &e->ws_xb, &e->ws_q, &e->ws_k, &e->ws_vt, &e->ws_ctx, &e->ws_y, &e->ws_h, &e->ws_seq, &e->ws_ids, &e->ws_mask, &e->ws_out, &e->ws_cls, &e->ws_stats, &e->ws_yb, &e->ws_part, &e->ws_idstats,
+                       &e->ws_gids, &e->ws_gmask, &e->ws_gout})
         b->release();
     if (e->h_pin) (void)hipHostFree(e->h_pin);
     if (e->h_len) (void)hipHostFree(e->h_len);
@@ -1718,6 +1824,7 @@ int hac_encoder_set_weight(hac_encoder *e, const char *name, const float *data, 
 int hac_encoder_finalize(hac_encoder *e) {
     if (!e) return fail(HAC_ERR_INVALID, "null encoder");
     DeviceGuard g(e->device);
+    drop_graphs(e);   // captured launches hold the old weights' pointers
     const hac_encoder_config &c = e->cfg;
     const std::string p = "roberta.embeddings.";
     HAC_TRY(get_raw(e, p + "word_embeddings.weight", (size_t)c.vocab * H, &e->word));
@@ -1852,6 +1959,9 @@ int hac_encoder_set_option(hac_encoder *e, const char *name, const char *value) 
         const long t = strtol(value, &end, 10);
         if (end == value || *end || t < 0 || t > 15) return fail(HAC_ERR_INVALID, "encoder option g8_split = '%s': a bit mask 0..15", value);
         e->g8_split = (int)t;
+    } else if (n == "graph") {
+        if (v != "auto" && v != "off") return fail(HAC_ERR_INVALID, "encoder option graph = '%s': auto | off", value);
+        e->graph_mode = v == "off" ? 0 : -1;
     } else if (n == "max_tokens") {
         char *end = nullptr;
         const long t = strtol(value, &end, 10);
@@ -1865,8 +1975,8 @@ int hac_encoder_set_option(hac_encoder *e, const char *name, const char *value) 
 
 const char *hac_encoder_last_plan(hac_encoder *e) {
     if (!e) return "none";
-    snprintf(e->last_plan, sizeof e->last_plan, "gemm=%s attn=%s sub_batches=%d rows=%ld", e->plan_gemm, e->attn_mode ? "twopass" : "stream",
-             e->plan_sub_batches, e->plan_rows);
+    snprintf(e->last_plan, sizeof e->last_plan, "gemm=%s attn=%s sub_batches=%d rows=%ld graph=%s", e->plan_gemm, e->attn_mode ? "twopass" : "stream",
+             e->plan_sub_batches, e->plan_rows, e->plan_graph);
     return e->last_plan;
 }
 

@@ -22,18 +22,45 @@ import numpy as np
 logger = logging.getLogger(__name__)
 
 
-def iter_embedding_blocks(passage_embeddings_dir, passage_block_num, mmap=True):
+def _load_block(passage_embeddings_dir, block_id, mmap, readahead):
+    from .passages import read_embedding_block
+    emb, ids = read_embedding_block(passage_embeddings_dir, block_id, mmap=mmap)
+    if readahead and isinstance(emb, np.memmap):
+        # ask the kernel to start reading the payload now (asynchronous read-ahead into the page cache): by the time add()
+        # walks these pages -- pageable -> pinned staging -> H2D, double-buffered inside hac_index_add -- they are resident
+        try:
+            import mmap as _mmap
+            emb._mmap.madvise(_mmap.MADV_WILLNEED)
+        except Exception:
+            pass
+    return emb, np.asarray(ids)
+
+
+def iter_embedding_blocks(passage_embeddings_dir, passage_block_num, mmap=True, prefetch=True):
     """Yield (emb float32 [n,768], ids int64 [n]) for block 0,1,… ; stops at the first
     block that cannot be loaded, like the reference's bare ``except: break`` (:94-95).
     mmap=True maps the pickled ndarray payload in place (haconvdr_amd.passages) instead of copying
-    the 7.7 GB block through ``pickle.load`` — the reference's dominant wall time at search."""
-    from .passages import read_embedding_block
-    for block_id in range(passage_block_num):
-        try:
-            emb, ids = read_embedding_block(passage_embeddings_dir, block_id, mmap=mmap)
-        except Exception:
-            break
-        yield emb, np.asarray(ids)
+    the 7.7 GB block through ``pickle.load`` — the reference's dominant wall time at search.
+    prefetch=True opens block b+1 on a background thread and starts its read-ahead while the caller still works on
+    block b (its add(): the H2D of 7.7 GB; in the reference's own loop also its search, :98-122): disk and PCIe overlap."""
+    if not prefetch or passage_block_num <= 1:
+        for block_id in range(passage_block_num):
+            try:
+                yield _load_block(passage_embeddings_dir, block_id, mmap, False)
+            except Exception:
+                break
+        return
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        nxt = pool.submit(_load_block, passage_embeddings_dir, 0, mmap, True)
+        for block_id in range(passage_block_num):
+            try:
+                cur = nxt.result()
+            except Exception:
+                break
+            if block_id + 1 < passage_block_num:
+                nxt = pool.submit(_load_block, passage_embeddings_dir, block_id + 1, mmap, True)
+            yield cur
 
 
 def _with_last_flag(it):

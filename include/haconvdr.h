@@ -198,15 +198,21 @@ int hac_encoder_forward_device(hac_encoder *enc, const void *ids_dev, const void
  * kernels with separate LayerNorm passes) | "8phase" (the large-batch ping-pong kernel with folded LayerNorms whenever
  * the batch has a whole 256-row tile); "attn" = "stream" (persistent single-pass attention kernels, the default) |
  * "twopass" (one workgroup per (sequence, head), exact row maxima first: the cross-check of the tests);
+ * "graph" = "auto" (default) | "off": batches of at most 16384 padded rows (the reference's own call shape is 4 queries per GPU,
+ * src/test_HAConvDR_topiocqa.py:173,406: ~110 launches for ~0.4 TFLOP) are captured ONCE per (B, L, elem_bytes, options) into a HIP
+ * graph over private input / output buffers and replayed -- per call one graph launch and three small device copies; the first call
+ * of a shape runs plain launches (it sizes the workspaces), the second captures, later ones replay; results are the same bits as
+ * with "off".  Not used while profiling is on or while the caller's stream is itself capturing;
  * "max_tokens" = packed rows per sub-batch (integer >= 4096); "g8_split" = bit mask 0..15 (development: which kernel
  * classes -- bit 0 QKV, 1 out-proj, 2 FFN-up, 3 FFN-down -- run the operand-split loop of the large-batch GEMM, default
  * 15; 0 = round 2's loop: same results bit for bit).  Any other name or value is HAC_ERR_INVALID (never a
  * silent default).  HAC_ENC_GEMM gives the default of "gemm" and is read once, in hac_encoder_create.
  * "auto" decides ONCE per forward call, from the rows of the whole batch: every sub-batch of a call runs the same
- * GEMM family, so a sequence's embedding does not depend on the sub-batch it fell into. */
+ * GEMM family and tile size, so a sequence's embedding does not depend on the sub-batch it fell into. */
 int hac_encoder_set_option(hac_encoder *enc, const char *name, const char *value);
-/* What the most recent forward ran: "gemm=gemm8|classic256|classic128 attn=stream|twopass sub_batches=N rows=R"
- * (tests and bench.py assert the kernel family they mean to check). */
+/* What the most recent forward ran: "gemm=gemm8|classic256|classic128 attn=stream|twopass sub_batches=N rows=R graph=off|eager-first|replay"
+ * (tests and bench.py assert the kernel family they mean to check).  The GEMM family and, with the classic kernels, the tile
+ * size are chosen once per call, from the rows of the whole batch: every sub-batch runs the same kernels. */
 const char *hac_encoder_last_plan(hac_encoder *enc);
 
 /* Profiling aid for bench.py: hipEvent pairs recorded on the launch stream (no host sync).  mask bit 0:

@@ -1,4 +1,4 @@
-"""One rank of the world_size-2 gloo test of the sharded search plumbing (CPU, test doubles)."""
+"""One rank of the gloo tests (world 2 and world 8) of the sharded search plumbing (CPU, test doubles)."""
 import os
 import sys
 
@@ -30,6 +30,18 @@ def main():
     ok = np.array_equal(I, mI) and np.array_equal(D.astype(np.float64), mD)
     oD, oI = oracle.flat_ip_search(x, q, k)
     ok = ok and np.array_equal(I, ids[oI]) and np.array_equal(D, oD)
+    # the step of `bench.py --gpus N` with a query count the ranks do not divide: every rank "encodes" ceil(nq / N) queries
+    # (its slab of the query matrix, the last slab partly padding), ONE all-gather brings all of them to every rank, the
+    # first nq rows are searched over the local shard, ONE all-gather of packed keys + merge finishes the step
+    nq_loc = (nq + world - 1) // world
+    slab = torch.zeros((nq_loc, q.shape[1]), dtype=torch.float32)
+    mine = q[rank * nq_loc:min(nq, (rank + 1) * nq_loc)]
+    slab[:len(mine)] = torch.from_numpy(mine)
+    allq = torch.empty((world * nq_loc, q.shape[1]), dtype=torch.float32)
+    dist.all_gather_into_tensor(allq, slab)
+    ok = ok and np.array_equal(allq[:nq].numpy(), q)
+    D2, I2 = s.search(allq[:nq], k)
+    ok = ok and np.array_equal(I2, I) and np.array_equal(D2, D)
     flag = torch.tensor([1 if ok else 0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     dist.destroy_process_group()

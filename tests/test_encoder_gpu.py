@@ -494,3 +494,41 @@ def test_options_outside_the_documented_set_are_errors():
             idx.set_option(name, value)
     for name, value in (("split", "auto"), ("split_terms", "1"), ("scanq_nt", "0"), ("scanq_waves", "8"), ("seed_groups_max", "0")):
         idx.set_option(name, value)
+
+
+def test_small_batch_graph_replay_equals_plain_launches_and_the_oracle():
+    """The reference's own call shape (4 queries per GPU, src/test_HAConvDR_topiocqa.py:173,406) is launch-bound: its forward is
+    captured once into a HIP graph and replayed.  First call of a shape = plain launches, second = capture + replay, later =
+    replay; all the same bits as with graph = off, on fresh data each time (the graph reads private copies of the inputs);
+    a larger forward in between (workspaces regrow) must not leave a stale graph behind; 12 layers vs the fp32 oracle."""
+    import torch
+    from haconvdr_amd import synth
+    from haconvdr_amd.encoder import ANCEEncoder
+    from oracle import ance_oracle
+    sd = state_dict(12)
+    enc = ANCEEncoder.from_state_dict(sd)
+    ref_enc = ANCEEncoder.from_state_dict(sd)
+    ref_enc.set_option("graph", "off")
+    kinds = []
+    for rep in range(4):
+        ids, lens = synth.token_batch(900 + rep, 4, 512, min_len=64)
+        mask = (np.arange(512)[None, :] < lens[:, None]).astype(np.int64)
+        ids_t, mask_t = torch.from_numpy(ids.astype(np.int64)).cuda(), torch.from_numpy(mask).cuda()
+        out = enc(ids_t, mask_t).cpu().numpy()
+        kinds.append(dict(kv.split("=") for kv in enc.last_plan().split())["graph"])
+        ref = ref_enc(ids_t, mask_t).cpu().numpy()
+        assert dict(kv.split("=") for kv in ref_enc.last_plan().split())["graph"] == "off"
+        np.testing.assert_array_equal(out, ref)
+        if rep == 1:
+            # a bigger batch regrows the workspaces the captured launches point into
+            big_ids, big_lens = synth.token_batch(77, 48, 512, fixed_len=512)
+            enc(torch.from_numpy(big_ids.astype(np.int64)).cuda(), torch.ones((48, 512), dtype=torch.int64, device="cuda"))
+    assert kinds == ["eager-first", "replay", "replay", "replay"], kinds
+    o = ance_oracle.ance_forward(sd, ids.astype(np.int64), mask)
+    assert np.all(one_minus_cos(out, o) < COS_EXPECT), one_minus_cos(out, o)
+    # host entry point (numpy in / out) and int32 ids: a different key, same route
+    a = enc(ids.astype(np.int32), mask.astype(np.int32))
+    b = enc(ids.astype(np.int32), mask.astype(np.int32))
+    assert "graph=replay" in enc.last_plan()
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(a, out)

@@ -93,12 +93,14 @@ def _free_port():
     return p
 
 
-def test_sharded_search_gloo_world2(oracle):
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_search_gloo_world(world, oracle):
+    """World 2, and the eight ranks of BASELINE configs[3] (7 queries over 8 ranks: one rank encodes only padding)."""
     port = _free_port()
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OMP_NUM_THREADS="2")
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1" if world > 2 else "2")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gloo_worker.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=300)[0] for p in procs]
