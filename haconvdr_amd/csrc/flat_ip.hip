@@ -1084,6 +1084,9 @@ struct DeviceIndex {
         HAC_TRY(ws_err.reserve(16));   // (a new GrowBuf is zero)
         HAC_HIP(hipHostMalloc((void **)&h_err, 16, hipHostMallocDefault));
         h_err[0] = h_err[1] = 0u;
+        HAC_HIP(hipHostMalloc((void **)&h_plan, 16, hipHostMallocDefault));
+        h_plan[0] = h_plan[1] = 0u;
+        HAC_HIP(hipEventCreateWithFlags(&ev_plan, hipEventDisableTiming));
         static bool attr_done[64] = {false};
         if (device < 64 && !attr_done[device]) {
             HAC_HIP(hipFuncSetAttribute((const void *)scan16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1120,6 +1123,8 @@ struct DeviceIndex {
             b->release();
         if (h_fb) (void)hipHostFree(h_fb);
         if (h_err) (void)hipHostFree(h_err);
+        if (h_plan) (void)hipHostFree(h_plan);
+        if (ev_plan) (void)hipEventDestroy(ev_plan);
         for (int i = 0; i < 2; ++i) {
             if (h_stage[i]) (void)hipHostFree(h_stage[i]);
             if (stage_ev[i]) (void)hipEventDestroy(stage_ev[i]);
@@ -1160,6 +1165,7 @@ struct DeviceIndex {
         segs.swap(keep);
         ntotal = 0;
         segs_dirty = true;
+        half_image_unavailable = false;
         HAC_HIP(hipMemsetAsync(ws_norm.p, 0, 16, stream));
         HAC_HIP(hipMemsetAsync(ws_err.p, 0, 16, stream));
         HAC_HIP(hipStreamSynchronize(stream));
@@ -1211,14 +1217,30 @@ struct DeviceIndex {
     // prefilter path (+50 % of the corpus bytes, which an index that only ever scans with a few queries, or runs with
     // split = "0", never spends), extended here for rows added since to a segment that had none.  Segments that own an image
     // get their new rows' pieces from tile_rows_kernel directly.
+    // (auto mode: when the image does not fit -- +50 % of the corpus bytes on a nearly full HBM -- the images that were
+    // allocated are given back, the sticky allocation error is cleared, no search tries again until the next add / reset,
+    // and the exact fp32 kernels answer: search_keys.  split = "1" keeps the hard error.)
+    bool half_image_unavailable = false;
+    void drop_half_images() {
+        for (auto &s : segs) {
+            if (s.hbuf) (void)hipFree(s.hbuf);
+            s.hbuf = nullptr;
+            s.h_rows = 0;
+        }
+        segs_dirty = true;
+    }
     int ensure_half_image(hipStream_t st) {
         for (auto &s : segs) {
             if (s.rows == 0 || (s.hbuf && s.h_rows == s.rows)) continue;
             if (!s.hbuf) {
                 const size_t hbytes = (size_t)s.cap_rows * d * 2;
                 hipError_t e = hipMalloc((void **)&s.hbuf, hbytes);
-                if (e != hipSuccess) return fail(HAC_ERR_OOM, "hipMalloc(%zu) for the fp16 image of %lld rows failed: %s (split = \"0\" searches without it)", hbytes,
-                                                 (long long)s.cap_rows, hipGetErrorString(e));
+                if (e != hipSuccess) {
+                    s.hbuf = nullptr;
+                    (void)hipGetLastError();   // the failed allocation's error is sticky: the next HAC_HIP(hipGetLastError()) would report it
+                    return fail(HAC_ERR_OOM, "hipMalloc(%zu) for the fp16 image of %lld rows failed: %s (split = \"0\" searches without it)", hbytes,
+                                (long long)s.cap_rows, hipGetErrorString(e));
+                }
                 s.h_rows = 0;
                 segs_dirty = true;
             }
@@ -1283,6 +1305,7 @@ struct DeviceIndex {
         }
         ntotal += n;
         segs_dirty = true;
+        half_image_unavailable = false;   // (memory may have been freed since: the next eligible search tries again)
         return HAC_OK;
     }
 
@@ -1358,19 +1381,35 @@ struct DeviceIndex {
     // a device-decided prefilter search leaves its fallback count and err / bound on the device: plan() completes the text
     char plan_head[200] = "";
     bool plan_pending = false;
-    hipStream_t plan_stream = nullptr;
     int64_t plan_nq = 0;
+    // The status words of a device-decided search reach the host through a pinned copy enqueued on the CALLER's stream and
+    // a library-owned event behind it: plan() waits for that event only -- never for the caller's stream, which may be gone
+    // or capturing by the time someone asks.
+    hipEvent_t ev_plan = nullptr;
+    u32 *h_plan = nullptr;     // pinned [2]
+    // (called at the start of the next device-decided search too, so that the fallback count of a search nobody polled is
+    // not lost as long as it had completed by then)
+    void plan_collect(bool wait) {
+        if (!plan_pending || !ev_plan) return;
+        hipError_t e = wait ? hipEventSynchronize(ev_plan) : hipEventQuery(ev_plan);
+        if (e == hipErrorNotReady) {
+            (void)hipGetLastError();
+            return;
+        }
+        // (an error here = the search was captured into a graph: the event was never recorded for real and cannot be waited
+        // for; the pinned words then are those of the last replay that has completed -- synchronize the stream you replay on)
+        if (e != hipSuccess) (void)hipGetLastError();
+        float maxratio;
+        std::memcpy(&maxratio, &h_plan[1], 4);
+        snprintf(last_plan, sizeof last_plan, "%s fallback=%u/%lld err/bound=%.3g decided=device%s", plan_head, h_plan[0], (long long)plan_nq, (double)maxratio,
+                 e == hipSuccess ? "" : " (captured: as of the last completed replay)");
+        split_fallback_queries += h_plan[0];
+        plan_pending = false;
+    }
     const char *plan() {
         if (plan_pending) {
             DeviceGuard g(device);
-            u32 st2[2] = {0, 0};
-            if (hipStreamSynchronize(plan_stream) == hipSuccess && hipMemcpy(st2, ws_stat.p, 8, hipMemcpyDeviceToHost) == hipSuccess) {
-                float maxratio;
-                std::memcpy(&maxratio, &st2[1], 4);
-                snprintf(last_plan, sizeof last_plan, "%s fallback=%u/%lld err/bound=%.3g decided=device", plan_head, st2[0], (long long)plan_nq, (double)maxratio);
-                split_fallback_queries += st2[0];
-            }
-            plan_pending = false;
+            plan_collect(true);
         }
         return last_plan;
     }
@@ -1605,6 +1644,7 @@ struct DeviceIndex {
                           bool device_decides = false) {
         const int K2 = SPLIT_K2, C2 = SPLIT_C2;
         const int terms = level == 0 ? tune.split_terms : 3;   // split_terms = 3: tests pin the first level
+        plan_collect(false);                                   // an earlier device-decided search nobody asked about
         HAC_TRY(ensure_half_image(st));
         HAC_TRY(upload_segs(st));
         const u32 G = (u32)((ntotal + GROUP_ROWS - 1) / GROUP_ROWS);
@@ -1758,8 +1798,9 @@ struct DeviceIndex {
             snprintf(plan_head, sizeof plan_head, "split: scanh_kernel<%d> grid=(%ld,%d) NQ=%d K2=%d chunks=%d lds=%zu seed=%d", terms, P_last,
                      n_qtiles_last, SH_NQ, K2, n_chunks, lds, seeded);
             snprintf(last_plan, sizeof last_plan, "%s fallback=device-side/%lld", plan_head, (long long)nq);
+            HAC_HIP(hipMemcpyAsync(h_plan, ws_stat.p, 8, hipMemcpyDeviceToHost, st));
+            HAC_HIP(hipEventRecord(ev_plan, st));
             plan_pending = true;
-            plan_stream = st;
             plan_nq = nq;
             return HAC_OK;
         }
@@ -1828,8 +1869,15 @@ struct DeviceIndex {
             if (((uintptr_t)q_dev & 15) != 0) return fail(HAC_ERR_INVALID, "search: query pointer must be 16-byte aligned");
             if ((uint64_t)pos_base + (uint64_t)ntotal > 0xFFFFFFFFull) return fail(HAC_ERR_UNSUPPORTED, "row positions exceed 32 bits");
         }
-        if (nq > 0 && ntotal > 0 && split_eligible(nq, k))
-            return search_keys_split(q_dev, nq, k, keys_out, pos_base, st, 0, tune.split_decide < 0 ? device_entry : tune.split_decide == 1);
+        if (nq > 0 && ntotal > 0 && split_eligible(nq, k) && !(tune.split < 0 && half_image_unavailable)) {
+            const int rc_img = ensure_half_image(st);
+            if (rc_img == HAC_OK) return search_keys_split(q_dev, nq, k, keys_out, pos_base, st, 0, tune.split_decide < 0 ? device_entry : tune.split_decide == 1);
+            if (rc_img != HAC_ERR_OOM || tune.split == 1) return rc_img;
+            // auto: no room for the fp16 image -> the exact fp32 kernels answer, with the same bits
+            HAC_HIP(hipStreamSynchronize(st));   // (a half_image_kernel of an earlier segment may still run)
+            drop_half_images();
+            half_image_unavailable = true;
+        }
         for (int64_t off = 0; off < nq || off == 0; off += QUERY_CHUNK) {
             const int64_t n = std::min<int64_t>(QUERY_CHUNK, nq - off);
             HAC_TRY(search_keys_exact(q_dev + (size_t)off * d, n, k, keys_out + (size_t)off * k, pos_base, st));

@@ -63,12 +63,20 @@ struct GrowBuf {
         }
         if (e != hipSuccess) return fail(HAC_ERR_OOM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
         cap = want;
-        // A new buffer starts out as zeros, whatever the allocator recycled: several workspaces are sized for a capacity and
-        // filled up to a count that lives on the device, and what lies beyond the count must not depend on the process's
-        // history (a soak run of 2400 index lifetimes hung in the device-decided fallback on recycled memory; fresh pages,
-        // which is what a first search sees, are zero).  Growth is rare; the wait keeps the fill ahead of every stream.
-        if (hipMemset(p, 0, want) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess)
-            return fail(HAC_ERR_OOM, "hipMemset(%zu) of a new workspace failed", want);
+        // A NEW buffer starts out as zeros, whatever the allocator recycled (fresh pages, which is what a first search sees, are
+        // zero; recycled ones are not).  This is hygiene, not a guarantee: a buffer that is REUSED rather than regrown still holds
+        // what earlier calls left in it, so no kernel may read beyond a device-side count without masking (what fixed the hang a
+        // soak run found in the device-decided fallback: gather_rows_kernel zeroes the rows behind the count, padded queries'
+        // thresholds are NaN).  Growth is rare; the null-stream memset + wait keeps the fill ahead of every stream, which also
+        // means that a call that has to GROW a workspace synchronizes once (include/haconvdr.h: warm up at the largest shape
+        // before capturing a *_device call into a graph).
+        if (hipMemset(p, 0, want) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(p);
+            p = nullptr;
+            cap = 0;
+            return fail(HAC_ERR_HIP, "hipMemset(%zu) of a new workspace failed", want);
+        }
         return HAC_OK;
     }
     void release() {

@@ -100,7 +100,15 @@ int hac_index_add_device(hac_index *idx, const float *x_dev, int64_t n, void *hi
  * the segment table (re-uploaded by the first search after an add / reset, which does
  * synchronize once) and the fp16 image exist.  That image (+50 % of the corpus bytes in HBM)
  * is built by the first search that takes the screen; an index that never does (few queries
- * per call, or split = "0") never allocates it. */
+ * per call, or split = "0") never allocates it.  With split = "auto", when the image does not fit beside the corpus the
+ * exact fp32 kernels answer instead (same bits) and no search tries again until the next add / reset; split = "1"
+ * reports HAC_ERR_OOM.
+ * Before capturing a *_device search into a graph, run one search of the LARGEST shape (nq, k) you will capture: a call that
+ * has to grow a workspace allocates, zero-fills it on the null stream and waits for that fill (once per growth).
+ * Cost of the device-decided route: per chunk of 1024 queries a re-tiling of the failed queries, two memsets, a full-grid scan,
+ * a select and a scatter are launched even when no query failed (their workgroups exit at once), and failed queries go
+ * straight to the exact fp32 kernels, without the host route's three-product retry and threshold seeding: on tie-heavy or
+ * degenerate corpora, where many certificates fail, hac_index_search (host route) is the faster entry point. */
 int hac_index_search(hac_index *idx, const float *q, int64_t nq, int k, float *D, int64_t *I);
 /* Device/stream variant (single-device index).  id_map_dev (optional, int64
  * [ntotal]) maps row -> external id, fusing `passage_embedding2id[I]` (:110). */

@@ -1066,3 +1066,44 @@ def test_pass_bound_turns_a_runaway_candidate_loop_into_an_error():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert "SCANQ" in r.stdout and "SCANH" in r.stdout, r.stdout
+
+
+@pytest.mark.gpu
+def test_auto_mode_answers_with_the_exact_kernels_when_the_fp16_image_does_not_fit(oracle):
+    """in split = "auto" a search whose fp16 image (+50 % of the corpus bytes) cannot be allocated used to fail
+    with HAC_ERR_OOM although the exact fp32 kernels could answer it, and left a sticky HIP error behind.  Now: the exact
+    kernels answer (same bits), nothing is retried until the next add / reset, and the handle keeps working."""
+    import torch
+    from haconvdr_amd.index import FlatIPIndex
+    g = torch.Generator(device="cuda").manual_seed(4242)
+    n, nq, k = 1_000_000, 130, 10
+    x = torch.randn((n, 768), generator=g, device="cuda")
+    q = torch.randn((nq, 768), generator=g, device="cuda")
+    idx = FlatIPIndex(768)
+    idx.add_tensor(x)
+    D0, I0 = idx.search_tensor(q[:8], k)                       # few queries: exact kernels, sizes the small workspaces
+    torch.cuda.synchronize()
+    free, _ = torch.cuda.mem_get_info()
+    hog = torch.empty(max(0, free - (700 << 20)), dtype=torch.uint8, device="cuda")    # 1.5 GB of image no longer fit
+    try:
+        D, I = idx.search_tensor(q, k)                         # eligible for the prefilter by size (1.3e8 pairs)
+        torch.cuda.synchronize()
+        assert idx.last_plan().startswith("scanq_kernel"), idx.last_plan()
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+    D2, I2 = idx.search_tensor(q, k)                           # room again, but nothing is retried before an add / reset
+    torch.cuda.synchronize()
+    assert idx.last_plan().startswith("scanq_kernel"), idx.last_plan()
+    assert torch.equal(I, I2) and torch.equal(D, D2)
+    idx.add_tensor(x[:64].contiguous())
+    D3, I3 = idx.search_tensor(q, k)
+    torch.cuda.synchronize()
+    assert idx.last_plan().startswith("split:"), idx.last_plan()
+    idx.check_status()
+    sel = [0, 7, 64, 129]
+    xa = torch.cat([x, x[:64]]).cpu().numpy()
+    oD, oI = oracle.flat_ip_search(xa, q[sel].cpu().numpy(), k)
+    assert_same(D3[sel].cpu().numpy(), I3[sel].cpu().numpy(), oD, oI)
+    oD1, oI1 = oracle.flat_ip_search(xa[:n], q[sel].cpu().numpy(), k)
+    assert_same(D[sel].cpu().numpy(), I[sel].cpu().numpy(), oD1, oI1)
