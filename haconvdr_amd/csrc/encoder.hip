@@ -276,16 +276,21 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float *__restrict__ 
 // statistics.  The fp32 normalized row is never stored: its one consumer, the residual add of the next
 // EPI_RESID epilogue, recomputes (y - mean) * rstd * gamma + beta from y -- 0.40 GB less HBM traffic per
 // LayerNorm at 131 k tokens (1.0 -> 0.6 GB).
-__global__ __launch_bounds__(256) void ln_stats_rows_kernel(const float *__restrict__ y, const int *__restrict__ total_rows,
+// n_part > 0: the RESID GEMM in front ran split-K (GemmArgs::ksplit): y holds slice 0's rows, part the bare sums of slices
+// 1 .. n_part; they are added here, in slice order, and the complete row is written back to y (it is the next residual).
+__global__ __launch_bounds__(256) void ln_stats_rows_kernel(float *__restrict__ y, const int *__restrict__ total_rows,
                                                             const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
-                                                            float2 *__restrict__ stats, bf16 *__restrict__ x_bf) {
+                                                            float2 *__restrict__ stats, bf16 *__restrict__ x_bf,
+                                                            const float *__restrict__ part = nullptr, int n_part = 0, size_t part_stride = 0) {
     const int lane = threadIdx.x & 63;
     const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= (size_t)*total_rows) return;
     float v[12];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const f4v a = *reinterpret_cast<const f4v *>(y + row * H + i * 256 + lane * 4);
+        f4v a = *reinterpret_cast<const f4v *>(y + row * H + i * 256 + lane * 4);
+        for (int sp = 0; sp < n_part; ++sp) a += *reinterpret_cast<const f4v *>(part + sp * part_stride + row * H + i * 256 + lane * 4);
+        if (n_part) *reinterpret_cast<f4v *>(y + row * H + i * 256 + lane * 4) = a;
         v[i * 4 + 0] = a.x;
         v[i * 4 + 1] = a.y;
         v[i * 4 + 2] = a.z;
@@ -333,6 +338,14 @@ struct GemmArgs {
     const float *rgamma, *rbeta;   // EPI_RESID with rstats: that LayerNorm's affine
     float *y;             // EPI_RESID: [Mp][768] fp32
     bf16 *h;              // EPI_GELU: [Mp][N] bf16
+    // EPI_RESID, small batches: split-K.  With ksplit = S > 1 an output tile is S work items, slice s accumulating k-tiles
+    // [s KT/S, (s+1) KT/S): slice 0 writes acc + bias + residual to y as always, slice s >= 1 its bare partial sums to
+    // part[(s-1) * part_stride ..]; the LayerNorm pass that follows every RESID GEMM (ln_stats_rows_kernel) adds them up in a
+    // fixed order (deterministic) and writes y back.  16 row tiles x 6 column tiles of a 4 x 512 batch are 96 work items for 256
+    // CUs, each walking all of K = 3072: split four ways the same GEMM is 384 items a quarter as long.
+    int ksplit;
+    float *part;
+    size_t part_stride;
 };
 
 // erf GELU (hidden_act = "gelu"): 0.5 x (1 + erf(x / sqrt 2)).  erf(z) = z P(z^2) on |z| <= 3, P of degree 8
@@ -381,7 +394,8 @@ __global__ __launch_bounds__(TMT * 128, 2) void gemm_bf16_nt_kernel(GemmArgs g) 
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K = g.K, KT = K / BK;
     const int nx = g.N / BN;
-    const int n_tiles = ((*g.total_rows + BM - 1) / BM) * nx;
+    const int S = (EPI == EPI_RESID && g.ksplit > 1) ? g.ksplit : 1, KTs = KT / S;   // split-K slices (RESID, small batches), k-tiles per slice
+    const int n_tiles = ((*g.total_rows + BM - 1) / BM) * nx * S;
     // XCD-aware tile lists: workgroups are dealt round-robin over the 8 XCDs; XCD x owns the contiguous
     // run [x*n/8, (x+1)*n/8) of tiles (consecutive tiles share the A rows -> L2 reuse of activations)
     // and its workgroups take them round-robin.
@@ -402,8 +416,9 @@ __global__ __launch_bounds__(TMT * 128, 2) void gemm_bf16_nt_kernel(GemmArgs g) 
     const int sch_even = (lane & 7) ^ (srow >> 1), sch_odd = sch_even ^ 4;
     const size_t lane_src_e = (size_t)(w * 32 + srow) * K + sch_even * 8;
     const size_t lane_src_o = (size_t)(w * 32 + srow) * K + sch_odd * 8;
-    auto stage = [&](int buf, int t, int kt) {
-        const int m0s = (t / nx) * BM, n0s = (t % nx) * BN;
+    auto stage = [&](int buf, int t, int kt) {   // kt: absolute k-tile
+        const int tt = EPI == EPI_RESID ? t / S : t;
+        const int m0s = (tt / nx) * BM, n0s = (tt % nx) * BN;
         const bf16 *gA = g.A + (size_t)m0s * K + kt * BK;
         const bf16 *gW = g.W + (size_t)n0s * K + kt * BK;
         unsigned char *sb = smem + buf * STAGE + w * 4096;
@@ -424,10 +439,11 @@ __global__ __launch_bounds__(TMT * 128, 2) void gemm_bf16_nt_kernel(GemmArgs g) 
     float *patch = reinterpret_cast<float *>(smem + 2 * STAGE) + w * 1024;  // [16 rows][64 cols] fp32, wave-private
 
     int cur = 0;
-    stage(0, tile, 0);
+    stage(0, tile, EPI == EPI_RESID ? (tile % S) * KTs : 0);
     __syncthreads();
     for (; tile < run_hi; tile += per_xcd) {
-        const int m0 = (tile / nx) * BM, n0 = (tile % nx) * BN;
+        const int otile = EPI == EPI_RESID ? tile / S : tile, slice = EPI == EPI_RESID ? tile - otile * S : 0, kb = slice * KTs;
+        const int m0 = (otile / nx) * BM, n0 = (otile % nx) * BN;
         const int next_tile = tile + per_xcd;
         // Two accumulator forms.  S16 (the 256^2 tile): v_mfma_f32_16x16x32_bf16, 8 x 4 tiles of 16x16 per wave;
         // same FLOPs, LDS traffic and matrix-pipe cycles as the 32x32x16 form, but the part holds a higher
@@ -450,9 +466,9 @@ __global__ __launch_bounds__(TMT * 128, 2) void gemm_bf16_nt_kernel(GemmArgs g) 
                     for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
         }
 
-        for (int kt = 0; kt < KT; ++kt) {
-            if (kt + 1 < KT) stage(cur ^ 1, tile, kt + 1);
-            else if (next_tile < run_hi) stage(cur ^ 1, next_tile, 0);
+        for (int kt = 0; kt < KTs; ++kt) {
+            if (kt + 1 < KTs) stage(cur ^ 1, tile, kb + kt + 1);
+            else if (next_tile < run_hi) stage(cur ^ 1, next_tile, EPI == EPI_RESID ? (next_tile % S) * KTs : 0);
             const unsigned char *sc = smem + cur * STAGE;
             if constexpr (S16) {
                 // lane (m = lane&15, kg = lane>>4): A/B fragment = row (tile*16 + m), chunk (4*ks32 + kg) ^ f(row);
@@ -508,7 +524,9 @@ __global__ __launch_bounds__(TMT * 128, 2) void gemm_bf16_nt_kernel(GemmArgs g) 
         // 16x64 sub-tile at a time through its private LDS patch and then touches global memory
         // row-wise with 16-byte accesses.  (The next tile's first k-step is already in LDS.)
         const int ncol0 = n0 + wn * 64;
-        const float bias0 = g.bias[ncol0 + r], bias1 = g.bias[ncol0 + 32 + r];
+        const bool partial = EPI == EPI_RESID && slice > 0;   // (workgroup-uniform) a split-K slice beyond the first: bare sums
+        const float bias0 = partial ? 0.f : g.bias[ncol0 + r], bias1 = partial ? 0.f : g.bias[ncol0 + 32 + r];
+        [[maybe_unused]] float *const y_out = partial ? g.part + (size_t)(slice - 1) * g.part_stride : g.y;
         if (EPI == EPI_QKV && n0 >= 2 * H) {
             // V goes out in 16-key groups ([Mp/16][768][16]) for the attention kernel's LDS-DMA: a lane holds
             // 4 consecutive tokens of one feature, i.e. 8 contiguous bytes of that layout.
@@ -555,7 +573,7 @@ __global__ __launch_bounds__(TMT * 128, 2) void gemm_bf16_nt_kernel(GemmArgs g) 
         float bias16[4];
         if constexpr (S16) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bias16[j] = g.bias[ncol0 + j * 16 + (lane & 15)];
+            for (int j = 0; j < 4; ++j) bias16[j] = partial ? 0.f : g.bias[ncol0 + j * 16 + (lane & 15)];
         }
 #pragma unroll
         for (int a = 0; a < TMT; ++a) {
@@ -567,8 +585,8 @@ __global__ __launch_bounds__(TMT * 128, 2) void gemm_bf16_nt_kernel(GemmArgs g) 
                     const size_t mr = (size_t)m0 + wm * (32 * TMT) + a * 32 + half * 16;
 #pragma unroll
                     for (int it = 0; it < 4; ++it)
-                        rs[it] = *reinterpret_cast<const f4v *>(g.resid + (mr + it * 4 + (lane >> 4)) * H + ncol0 + (lane & 15) * 4);
-                    if (g.rstats) {   // deferred LayerNorm of the residual rows (ln_stats_rows_kernel)
+                        rs[it] = partial ? (f4v){0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f4v *>(g.resid + (mr + it * 4 + (lane >> 4)) * H + ncol0 + (lane & 15) * 4);
+                    if (g.rstats && !partial) {   // deferred LayerNorm of the residual rows (ln_stats_rows_kernel)
                         const f4v gam = *reinterpret_cast<const f4v *>(g.rgamma + ncol0 + (lane & 15) * 4);
                         const f4v bet = *reinterpret_cast<const f4v *>(g.rbeta + ncol0 + (lane & 15) * 4);
 #pragma unroll
@@ -603,7 +621,7 @@ __global__ __launch_bounds__(TMT * 128, 2) void gemm_bf16_nt_kernel(GemmArgs g) 
                         const int row = it * 4 + (lane >> 4), c4 = (lane & 15) * 4;
                         const f4v v = *reinterpret_cast<const f4v *>(patch + row * 64 + c4);
                         const size_t off = (mrow + row) * H + ncol0 + c4;
-                        *reinterpret_cast<f4v *>(g.y + off) = v + rs[it];
+                        *reinterpret_cast<f4v *>(y_out + off) = v + rs[it];
                     }
                 } else {
 #pragma unroll
@@ -1152,17 +1170,19 @@ constexpr int CLS_NS = 64;    // output features per workgroup (16 per wave): gr
 // microseconds.  A sequence's arithmetic (products, their order, the reduction) does not depend on its neighbours.
 
 // ANCE head, first half: e[b][n] = W_h[n,:] . x[b,:] + b_h[n] in fp32 (models.py:43)
+// ns: output features per workgroup (gridDim.y = H / ns): CLS_NS for large batches; 8 for a handful of sequences, where 12
+// workgroups of 64 features each took 40 us of a 1.5 ms forward
 __global__ __launch_bounds__(256) void cls_head_proj_kernel(const float *__restrict__ x, SeqInfo s, int compact, int B, const float *__restrict__ Wh,
-                                                            const float *__restrict__ bh, float *__restrict__ e_out) {
+                                                            const float *__restrict__ bh, float *__restrict__ e_out, int ns) {
     __shared__ float xs[CLS_SB][H];
-    const int b0 = blockIdx.x * CLS_SB, n0 = blockIdx.y * CLS_NS, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b0 = blockIdx.x * CLS_SB, n0 = blockIdx.y * ns, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nb = min(CLS_SB, B - b0);
     for (int j = 0; j < CLS_SB; ++j) {
         const float *xr = x + (size_t)(compact ? b0 + j : s.off[min(b0 + j, B - 1)]) * H;
         for (int i = tid; i < H; i += 256) xs[j][i] = j < nb ? xr[i] : 0.f;
     }
     __syncthreads();
-    for (int n = n0 + w; n < n0 + CLS_NS; n += 4) {
+    for (int n = n0 + w; n < n0 + ns; n += 4) {
         const float *wr = Wh + (size_t)n * H;
         float wv[12];
 #pragma unroll
@@ -1286,6 +1306,7 @@ struct hac_encoder {
     bool finalized = false;
     // workspace
     GrowBuf ws_x, ws_xb, ws_q, ws_k, ws_vt, ws_ctx, ws_y, ws_h, ws_seq, ws_ids, ws_mask, ws_out, ws_cls, ws_stats;
+    GrowBuf ws_ksplit;                    // classic path, small batches: split-K partial sums of the RESID GEMMs
     GrowBuf ws_yb, ws_part, ws_idstats;   // gemm8 path: bf16 copy of the attention-block rows, row-sum partials, (0, 1) statistics
     size_t idstats_rows = 0;
     int attn_mode = 0;                    // 0: streaming single-pass attention; 1: two-pass kernels (cross-check)
@@ -1437,6 +1458,23 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
     HAC_HIP(hipGetLastError());
     const int bt = big ? 256 : 128;
     const size_t lds = (size_t)4 * bt * 128 + (size_t)(big ? 8 : 4) * 4096;   // 2 stages + per-wave patches
+    // Small batches (128^2 tiles): the two RESID GEMMs have only Mp / 128 x 6 output tiles -- 96 for the reference's 4 x 512 query
+    // batch, on 256 CUs -- so their K loop is split until ~1.5 work items per CU exist (slices of at least three k-tiles)
+    auto pick_ksplit = [&](int K) {
+        if (g8 || big) return 1;
+        const long tiles = (Mp / 128) * (H / 128);
+        const int KT = K / 64;
+        int S = 1;
+        for (int cand : {2, 3, 4, 6, 8, 12, 16}) {
+            if (tiles * S >= e->n_cu * 3 / 2) break;
+            if (KT % cand == 0 && KT / cand >= 3) S = cand;
+        }
+        return S;
+    };
+    const int ks_out = pick_ksplit(H), ks_down = pick_ksplit(FF);
+    const size_t part_stride = (size_t)Mp * H;
+    if (std::max(ks_out, ks_down) > 1) HAC_TRY(e->ws_ksplit.reserve((size_t)(std::max(ks_out, ks_down) - 1) * part_stride * 4));
+    float *kpart = (float *)e->ws_ksplit.p;
     const dim3 blk(big ? 512 : 256);
     const unsigned n_wg = (unsigned)(e->n_cu * (big ? 1 : 2));
 #define HAC_GEMM(EPI, CLS)                                                            \
@@ -1552,18 +1590,22 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
             // attention output projection + residual, LN statistics
             g.A = ctx; g.W = w.wo; g.bias = w.bo; g.N = H; g.K = H; g.resid = x; g.y = y;
             g.rstats = defer_in ? statsF : nullptr; g.rgamma = ln2g_prev; g.rbeta = ln2b_prev;
+            g.ksplit = ks_out; g.part = kpart; g.part_stride = part_stride;
             HAC_GEMM(EPI_RESID, HAC_ENC_CLASS_OUTPROJ);
+            g.ksplit = 1;
             HAC_TRY(prof_begin(e, 1 + HAC_ENC_CLASS_LN, st));
-            ln_stats_rows_kernel<<<dim3((unsigned)(Mp / 4)), dim3(256), 0, st>>>(y, total, w.ln1g, w.ln1b, c.ln_eps, statsA, xb);
+            ln_stats_rows_kernel<<<dim3((unsigned)(Mp / 4)), dim3(256), 0, st>>>(y, total, w.ln1g, w.ln1b, c.ln_eps, statsA, xb, kpart, ks_out - 1, part_stride);
             HAC_TRY(prof_end(e, 1 + HAC_ENC_CLASS_LN, st));
             // FFN
             g.A = xb; g.W = w.w1; g.bias = w.b1; g.N = FF; g.K = H; g.h = h;
             HAC_GEMM(EPI_GELU, HAC_ENC_CLASS_FFN_UP);
             g.A = h; g.W = w.w2; g.bias = w.b2; g.N = H; g.K = FF; g.resid = y; g.y = x;
             g.rstats = statsA; g.rgamma = w.ln1g; g.rbeta = w.ln1b;
+            g.ksplit = ks_down; g.part = kpart; g.part_stride = part_stride;
             HAC_GEMM(EPI_RESID, HAC_ENC_CLASS_FFN_DOWN);
+            g.ksplit = 1;
             HAC_TRY(prof_begin(e, 1 + HAC_ENC_CLASS_LN, st));
-            ln_stats_rows_kernel<<<dim3((unsigned)(Mp / 4)), dim3(256), 0, st>>>(x, total, w.ln2g, w.ln2b, c.ln_eps, statsF, xb);
+            ln_stats_rows_kernel<<<dim3((unsigned)(Mp / 4)), dim3(256), 0, st>>>(x, total, w.ln2g, w.ln2b, c.ln_eps, statsF, xb, kpart, ks_down - 1, part_stride);
             HAC_TRY(prof_end(e, 1 + HAC_ENC_CLASS_LN, st));
         } else {
             // only the <s> row of every sequence continues (B rows instead of T): same kernels, compact matrices
@@ -1585,7 +1627,8 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
 #undef HAC_GEMM
     HAC_TRY(prof_end(e, 0, st));
     // ANCE head on the compact <s> rows: projection (y_c is free again), then LayerNorm_768 and the per-sequence error flag
-    cls_head_proj_kernel<<<dim3((unsigned)((B + CLS_SB - 1) / CLS_SB), H / CLS_NS), dim3(256), 0, st>>>(x_c, s, 1, B, e->wh, e->bh, y_c);
+    const int head_ns = B <= 64 ? 8 : CLS_NS;
+    cls_head_proj_kernel<<<dim3((unsigned)((B + CLS_SB - 1) / CLS_SB), H / head_ns), dim3(256), 0, st>>>(x_c, s, 1, B, e->wh, e->bh, y_c, head_ns);
     cls_head_norm_kernel<<<dim3((unsigned)B), dim3(256), 0, st>>>(y_c, s, e->ng, e->nb, 1e-5f, out_dev);
     HAC_HIP(hipGetLastError());
     e->plan_sub_batches += 1;
@@ -1599,7 +1642,7 @@ constexpr long GRAPH_MAX_ROWS = 16384;   // beyond this a forward is millisecond
 uint64_t ws_signature(const hac_encoder *e) {
     uint64_t h = 1469598103934665603ull;
     for (const GrowBuf *b : {&e->ws_x, &e->ws_xb, &e->ws_q, &e->ws_k, &e->ws_vt, &e->ws_ctx, &e->ws_y, &e->ws_h, &e->ws_seq, &e->ws_cls, &e->ws_stats,
-                             &e->ws_yb, &e->ws_part, &e->ws_idstats, &e->ws_gids, &e->ws_gmask, &e->ws_gout})
+                             &e->ws_yb, &e->ws_part, &e->ws_idstats, &e->ws_gids, &e->ws_gmask, &e->ws_gout, &e->ws_ksplit})
         h = (h ^ (uint64_t)(uintptr_t)b->p) * 1099511628211ull;
     return h;
 }
@@ -1790,7 +1833,7 @@ void hac_encoder_destroy(hac_encoder *e) {
     }
     drop_graphs(e);
     for (GrowBuf *b : {&e->ws_x, &e->ws_xb, &e->ws_q, &e->ws_k, &e->ws_vt, &e->ws_ctx, &e->ws_y, &e->ws_h, &e->ws_seq, &e->ws_ids, &e->ws_mask, &e->ws_out, &e->ws_cls, &e->ws_stats, &e->ws_yb, &e->ws_part, &e->ws_idstats,
-                       &e->ws_gids, &e->ws_gmask, &e->ws_gout})
+                       &e->ws_gids, &e->ws_gmask, &e->ws_gout, &e->ws_ksplit})
         b->release();
     if (e->h_pin) (void)hipHostFree(e->h_pin);
     if (e->h_len) (void)hipHostFree(e->h_len);

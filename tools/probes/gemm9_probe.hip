@@ -21,7 +21,7 @@ template <typename F> float timeit(F f, int iters) {
   float ms; CK(hipEventElapsedTime(&ms,e0,e1)); CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1)); return ms/iters;
 }
 int main(){
-  const int M = 131328;   // 171 x 768
+  const int M = getenv("G9_M") ? atoi(getenv("G9_M")) : 131328;   // a multiple of 768
   std::mt19937 rng(1); std::normal_distribution<float> nd(0.f,1.f);
   auto mk = [&](size_t n, float sc){ std::vector<float> h(n); for(auto&v:h) v=nd(rng)*sc; float* d; CK(hipMalloc(&d,n*4)); CK(hipMemcpy(d,h.data(),n*4,hipMemcpyHostToDevice)); bf16* b; CK(hipMalloc(&b,n*2)); f32_to_bf16_kernel<<<(n+255)/256,256>>>(d,b,n); CK(hipDeviceSynchronize()); CK(hipFree(d)); return b; };
   auto mkf = [&](size_t n, float sc, float off){ std::vector<float> h(n); for(auto&v:h) v=off+nd(rng)*sc; float* d; CK(hipMalloc(&d,n*4)); CK(hipMemcpy(d,h.data(),n*4,hipMemcpyHostToDevice)); return d; };
