@@ -1339,6 +1339,8 @@ struct hac_encoder {
     // launches, not arithmetic: ~110 kernels for ~0.4 TFLOP.  Their forward is captured ONCE per (B, L, options) into a HIP
     // graph over private input / output buffers and replayed: one graph launch + three small copies per call.
     int graph_mode = -1;                  // -1: small batches without profiling, 0: never
+    int ksplit_mode = -1;                 // -1: split-K of the small-batch RESID GEMMs by tile count, 0: never (tests that compare batches of different sizes bit for bit)
+    int plan_ks_out = 1, plan_ks_down = 1;
     struct GraphEntry {
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
@@ -1461,7 +1463,7 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
     // Small batches (128^2 tiles): the two RESID GEMMs have only Mp / 128 x 6 output tiles -- 96 for the reference's 4 x 512 query
     // batch, on 256 CUs -- so their K loop is split until ~1.5 work items per CU exist (slices of at least three k-tiles)
     auto pick_ksplit = [&](int K) {
-        if (g8 || big) return 1;
+        if (g8 || big || e->ksplit_mode == 0) return 1;
         const long tiles = (Mp / 128) * (H / 128);
         const int KT = K / 64;
         int S = 1;
@@ -1472,6 +1474,8 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
         return S;
     };
     const int ks_out = pick_ksplit(H), ks_down = pick_ksplit(FF);
+    e->plan_ks_out = ks_out;
+    e->plan_ks_down = ks_down;
     const size_t part_stride = (size_t)Mp * H;
     if (std::max(ks_out, ks_down) > 1) HAC_TRY(e->ws_ksplit.reserve((size_t)(std::max(ks_out, ks_down) - 1) * part_stride * 4));
     float *kpart = (float *)e->ws_ksplit.p;
@@ -1668,7 +1672,7 @@ int forward_graph(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, f
     HAC_TRY(e->ws_gmask.reserve(n_in));
     HAC_TRY(e->ws_gout.reserve(n_out));
     const uint64_t key = ((uint64_t)B << 40) | ((uint64_t)L << 24) | ((uint64_t)sizeof(IT) << 16) | ((uint64_t)(e->attn_mode & 1) << 8) |
-                         ((uint64_t)((e->gemm_mode + 1) & 3) << 4) | (uint64_t)(e->g8_split & 15);
+                         ((uint64_t)((e->gemm_mode + 1) & 3) << 4) | (uint64_t)(e->g8_split & 15) | ((uint64_t)(e->ksplit_mode & 1) << 12);
     hac_encoder::GraphEntry &ge = e->graphs[key];
     const IT *gids = (const IT *)e->ws_gids.p, *gmask = (const IT *)e->ws_gmask.p;
     float *gout = (float *)e->ws_gout.p;
@@ -2002,6 +2006,9 @@ int hac_encoder_set_option(hac_encoder *e, const char *name, const char *value) 
         const long t = strtol(value, &end, 10);
         if (end == value || *end || t < 0 || t > 15) return fail(HAC_ERR_INVALID, "encoder option g8_split = '%s': a bit mask 0..15", value);
         e->g8_split = (int)t;
+    } else if (n == "ksplit") {
+        if (v != "auto" && v != "off") return fail(HAC_ERR_INVALID, "encoder option ksplit = '%s': auto | off", value);
+        e->ksplit_mode = v == "off" ? 0 : -1;
     } else if (n == "graph") {
         if (v != "auto" && v != "off") return fail(HAC_ERR_INVALID, "encoder option graph = '%s': auto | off", value);
         e->graph_mode = v == "off" ? 0 : -1;
@@ -2018,8 +2025,8 @@ int hac_encoder_set_option(hac_encoder *e, const char *name, const char *value) 
 
 const char *hac_encoder_last_plan(hac_encoder *e) {
     if (!e) return "none";
-    snprintf(e->last_plan, sizeof e->last_plan, "gemm=%s attn=%s sub_batches=%d rows=%ld graph=%s", e->plan_gemm, e->attn_mode ? "twopass" : "stream",
-             e->plan_sub_batches, e->plan_rows, e->plan_graph);
+    snprintf(e->last_plan, sizeof e->last_plan, "gemm=%s attn=%s sub_batches=%d rows=%ld graph=%s ksplit=%d/%d", e->plan_gemm, e->attn_mode ? "twopass" : "stream",
+             e->plan_sub_batches, e->plan_rows, e->plan_graph, e->plan_ks_out, e->plan_ks_down);
     return e->last_plan;
 }
 

@@ -211,6 +211,10 @@ int hac_encoder_forward_device(hac_encoder *enc, const void *ids_dev, const void
  * graph over private input / output buffers and replayed -- per call one graph launch and three small device copies; the first call
  * of a shape runs plain launches (it sizes the workspaces), the second captures, later ones replay; results are the same bits as
  * with "off".  Not used while profiling is on or while the caller's stream is itself capturing;
+ * "ksplit" = "auto" (default) | "off": with few rows (the classic 128^2 kernels, fewer than ~1.5 output tiles per CU) the two
+ * residual GEMMs of a layer split their K loop over 2..16 work items per tile, the partial sums being added in a fixed order by
+ * the LayerNorm pass behind them: deterministic, but the summation order -- hence the last bits of an embedding -- then depends
+ * on the batch's row count (as it does between the "gemm" families); "off" restores one summation order for every small batch;
  * "max_tokens" = packed rows per sub-batch (integer >= 4096); "g8_split" = bit mask 0..15 (development: which kernel
  * classes -- bit 0 QKV, 1 out-proj, 2 FFN-up, 3 FFN-down -- run the operand-split loop of the large-batch GEMM, default
  * 15; 0 = round 2's loop: same results bit for bit).  Any other name or value is HAC_ERR_INVALID (never a
@@ -218,7 +222,7 @@ int hac_encoder_forward_device(hac_encoder *enc, const void *ids_dev, const void
  * "auto" decides ONCE per forward call, from the rows of the whole batch: every sub-batch of a call runs the same
  * GEMM family and tile size, so a sequence's embedding does not depend on the sub-batch it fell into. */
 int hac_encoder_set_option(hac_encoder *enc, const char *name, const char *value);
-/* What the most recent forward ran: "gemm=gemm8|classic256|classic128 attn=stream|twopass sub_batches=N rows=R graph=off|eager-first|replay"
+/* What the most recent forward ran: "gemm=gemm8|classic256|classic128 attn=stream|twopass sub_batches=N rows=R graph=off|eager-first|replay ksplit=S_out/S_down"
  * (tests and bench.py assert the kernel family they mean to check).  The GEMM family and, with the classic kernels, the tile
  * size are chosen once per call, from the rows of the whole batch: every sub-batch runs the same kernels. */
 const char *hac_encoder_last_plan(hac_encoder *enc);

@@ -169,6 +169,7 @@ def test_streaming_attention_many_items_per_workgroup(lo, hi, n_seq):
     outs = {}
     pick = [0, 1, n_seq // 2, n_seq - 1, int(np.argmin(lens)), int(np.argmax(lens))]
     enc.set_option("gemm", "classic")      # one GEMM family for the big and the six-sequence batch: bit-equal rows
+    enc.set_option("ksplit", "off")        # ... and one summation order (small batches would split the K loop of their residual GEMMs)
     try:
         for mode in ("twopass", "stream"):
             enc.set_option("attn", mode)
@@ -177,6 +178,7 @@ def test_streaming_attention_many_items_per_workgroup(lo, hi, n_seq):
     finally:
         enc.set_option("gemm", "auto")
         enc.set_option("attn", "stream")
+        enc.set_option("ksplit", "auto")
     assert np.isfinite(outs["stream"]).all()
     assert one_minus_cos(outs["stream"], outs["twopass"]).max() < COS_EXPECT
     np.testing.assert_array_equal(alone, outs["stream"][pick])
@@ -208,11 +210,20 @@ def test_batch_composition_invariance():
     g = np.load([p for p in GOLD if "l2_mixed" in p][0])
     enc = encoder(2)
     ids, mask = g["ids"].astype(np.int32), g["mask"].astype(np.int32)
-    full = enc(ids, mask)
-    perm = np.array([5, 0, 7, 2])
-    part = enc(ids[perm], mask[perm])
-    np.testing.assert_array_equal(part, full[perm])
-    np.testing.assert_array_equal(enc(ids[3:4, :128], mask[3:4, :128]), full[3:4])   # shorter padded length L
+    enc.set_option("ksplit", "off")   # batches of 8, 4 and 1 sequences bit for bit: one summation order (split-K goes by the row count)
+    try:
+        full = enc(ids, mask)
+        perm = np.array([5, 0, 7, 2])
+        part = enc(ids[perm], mask[perm])
+        np.testing.assert_array_equal(part, full[perm])
+        np.testing.assert_array_equal(enc(ids[3:4, :128], mask[3:4, :128]), full[3:4])   # shorter padded length L
+    finally:
+        enc.set_option("ksplit", "auto")
+    # with the K loop split by row count the same rows agree to rounding noise, and the same batch twice bit for bit
+    a, b = enc(ids[perm], mask[perm]), enc(ids[perm], mask[perm])
+    np.testing.assert_array_equal(a, b)
+    assert "ksplit=1/1" not in enc.last_plan(), enc.last_plan()
+    assert one_minus_cos(a, full[perm]).max() < 1e-5
 
 
 @pytest.mark.parametrize("gemm", ["classic", "8phase"])
@@ -222,6 +233,7 @@ def test_large_batch_subbatching(gemm):
     from haconvdr_amd import synth
     enc = encoder(2)
     enc.set_option("gemm", gemm)
+    enc.set_option("ksplit", "off")                                   # (the five-sequence batches below would split their K loops)
     try:
         ids, lens = synth.token_batch(31, 1500, 384, min_len=8)      # 576k padded rows, ~300k real: two length-sized sub-batches
         mask = (np.arange(384)[None, :] < lens[:, None]).astype(np.int32)
@@ -234,6 +246,7 @@ def test_large_batch_subbatching(gemm):
         np.testing.assert_array_equal(outf[[0, 450, 899]], enc(ids[[0, 450, 899]], full[:3]))
     finally:
         enc.set_option("gemm", "auto")
+        enc.set_option("ksplit", "auto")
     enc = encoder(2)
     ids, lens = synth.token_batch(31, 1500, 384, min_len=8)
     mask = (np.arange(384)[None, :] < lens[:, None]).astype(np.int32)
