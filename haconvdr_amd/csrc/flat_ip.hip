@@ -972,7 +972,16 @@ struct DeviceIndex {
         int seed_groups_max = 0;         // cap of the seeding pass of the prefilter scan, in 64-row groups; 0 = 14 sqrt(groups)
         int split_decide = -1;           // who reads the certificates: -1 by entry point (host API: host, *_device: device), 0 host, 1 device
         int debug_max_pass = 0;          // tests: pass bound of the candidate loops (0 = the kernels' own, which no legal input reaches)
+        int scan_passes = 0;             // prefilter scan: 0 by size, 1..3 pins the number of passes (threshold refreshes between them)
     } tune;
+    // passes of the prefilter's main scan (search_keys_split): a refresh costs a kernel tail + a selection (~0.1 ms), so only
+    // scans of several milliseconds are cut, and only with seeded thresholds (the refresh raises them in place)
+    int scan_passes(u32 G, u32 round_groups, bool seeded) const {
+        if (!seeded) return 1;
+        int n = tune.scan_passes > 0 ? tune.scan_passes : (G >= 98304u ? 3 : (G >= 49152u ? 2 : 1));   // >= 6.3M / 3.1M rows
+        while (n > 1 && (u32)(0.08 * G) / round_groups == 0) --n;
+        return n;
+    }
     void read_env() {
         if (const char *e = getenv("HAC_SPLIT")) tune.split = e[0] == '0' ? 0 : (e[0] == '1' ? 1 : -1);
         if (const char *e = getenv("HAC_SPLIT_TERMS")) tune.split_terms = e[0] == '3' ? 3 : 1;
@@ -1014,6 +1023,9 @@ struct DeviceIndex {
         } else if (n == "split_decide") {
             if (!one_of({"auto", "host", "device"})) return HAC_ERR_INVALID;
             tune.split_decide = v == "host" ? 0 : (v == "device" ? 1 : -1);
+        } else if (n == "scan_passes") {
+            if (!one_of({"auto", "1", "2", "3"})) return HAC_ERR_INVALID;
+            tune.scan_passes = v == "auto" ? 0 : atoi(v.c_str());
         } else if (n == "debug_max_pass") {
             char *end = nullptr;
             const long t = strtol(v.c_str(), &end, 10);
@@ -1655,7 +1667,7 @@ struct DeviceIndex {
         HAC_TRY(ws_qsplit.reserve((size_t)n_qtiles_max * SH_NQ * d * 2 * (terms == 3 ? 2 : 1)));
         HAC_TRY(ws_delta.reserve((size_t)(nq + SH_NQ) * 4));
         HAC_TRY(ws_cand.reserve((size_t)Pmax * SH_NQ * C2 * 8));          // P * n_qtiles <= n_cu workgroups
-        HAC_TRY(ws_partial.reserve((size_t)chunk * Pmax * K2 * 8));
+        HAC_TRY(ws_partial.reserve((size_t)chunk * Pmax * K2 * 8 * 3));
         HAC_TRY(ws_pcnt.reserve((size_t)chunk * 4));
         HAC_TRY(ws_thrglob.reserve(((size_t)n_qtiles_max * SH_NQ + THR_CTL_WORDS) * 4));
         HAC_TRY(ws_akeys.reserve((size_t)nq * K2 * 8));
@@ -1693,7 +1705,7 @@ struct DeviceIndex {
             long P = std::max<long>(1, n_cu / n_qtiles);
             if (P >= 8) P = P / 8 * 8;  // same-row workgroups of different query tiles share an XCD (L2)
             P = std::max<long>(1, std::min<long>(P, (G + SH_GPR - 1) / SH_GPR));
-            const long pstride = (long)P * K2;
+            const long pstride = (long)P * K2 * 3;   // a workgroup flushes at most K2 survivors per query and pass: up to three passes
             float *delta_c = (float *)ws_delta.p + off;
             u64 *akeys_c = (u64 *)ws_akeys.p + (size_t)off * K2;
             split_queries_kernel<<<dim3((unsigned)nq_pad), dim3(192), 0, st>>>(reinterpret_cast<const float4 *>(qc), (int)n, K4, terms,
@@ -1738,11 +1750,33 @@ struct DeviceIndex {
                 HAC_HIP(hipGetLastError());
                 thr_init = (const float *)ws_thr.p;
             }
-            a.n_items = G;
+            // The scan itself, in up to three passes over consecutive row ranges (big corpora, seeded thresholds).  A workgroup's own
+            // lists never reach their compaction mark (~100 candidates per query and row stream over a whole 25M-row scan), so
+            // within one launch the seeded threshold is all a query ever has: 0.07 % of the pairs pass it where K2 / rows would
+            // do, and parking + appending those candidates is ~12 % of the kernel.  Between passes the K2-th best s~ of everything
+            // found SO FAR (all row streams together: select_keys_kernel over the survivors flushed by the passes before) is a
+            // valid, much sharper bound: after 8 % of the rows ~3x fewer pairs pass, after 30 % ~8x fewer.
+            const int n_pass = scan_passes(G, round_groups, thr_init != nullptr);
+            u32 bounds[4] = {0u, 0u, 0u, G};
+            if (n_pass >= 2) bounds[1] = (u32)(0.08 * G) / round_groups * round_groups;
+            if (n_pass >= 3) bounds[2] = (u32)(0.30 * G) / round_groups * round_groups;
+            if (n_pass == 2) bounds[2] = G;
+            if (n_pass == 1) bounds[1] = bounds[2] = G;
             a.thr_init = thr_init;
-            if (terms == 3) scanh_kernel<3, false><<<grid, blk, lds, st>>>(a, sp);
-            else scanh_kernel<1, false><<<grid, blk, lds, st>>>(a, sp);
-            HAC_HIP(hipGetLastError());
+            for (int ps = 0; ps < n_pass; ++ps) {
+                a.g_first = bounds[ps];
+                a.n_items = bounds[ps + 1] - bounds[ps];
+                if (terms == 3) scanh_kernel<3, false><<<grid, blk, lds, st>>>(a, sp);
+                else scanh_kernel<1, false><<<grid, blk, lds, st>>>(a, sp);
+                HAC_HIP(hipGetLastError());
+                if (ps + 1 < n_pass) {   // refresh: ws_thr[q] = max(ws_thr[q], K2-th best s~ so far)
+                    select_keys_kernel<<<dim3((unsigned)n), dim3(256), (size_t)K2 * 8, st>>>((const u64 *)ws_partial.p, (size_t)pstride,
+                                                                                             (const u32 *)ws_pcnt.p, (u32)pstride, K2, K2, akeys_c, (float *)ws_thr.p,
+                                                                                             nullptr, 0, 0, 1, nullptr, nullptr, true);
+                    HAC_HIP(hipGetLastError());
+                }
+            }
+            a.g_first = 0;
             if (profiling) {
                 HAC_HIP(hipEventRecord(ev_pool[ev_used].second, st));
                 ++ev_used;

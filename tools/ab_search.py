@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Search timing for A/B runs of kernel variants (HAC_LIBRARY_PATH picks the library): the scan of 1000 queries over N rows.
-  HAC_LIBRARY_PATH=scratch/v/libX.so python tools/ab_search.py [rows] [reps]"""
+  HAC_LIBRARY_PATH=scratch/v/libX.so python tools/ab_search.py [rows] [reps] [option=value ...]"""
 import os
 import sys
 import time
@@ -19,6 +19,9 @@ def main():
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     dev = torch.device("cuda", 0)
     idx = FlatIPIndex(768)
+    opts = [a.split("=", 1) for a in sys.argv[3:]]
+    for name, value in opts:
+        idx.set_option(name, value)
     bench.fill_index(idx, 0, rows, dev, rows // 8)
     q = bench.gen_rows(0xBEEF, 1000, dev)
     for _ in range(2):
@@ -31,7 +34,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     ms = idx.profile_drain()
-    print(f"{os.environ.get('HAC_LIBRARY_PATH', 'in-tree')}: rows {rows} search {dt * 1e3:.3f} ms, scan kernels min {min(ms):.3f} med {np.median(ms):.3f} ms | {idx.last_plan()}", flush=True)
+    print(f"{os.environ.get('HAC_LIBRARY_PATH', 'in-tree')} {opts}: rows {rows} search {dt * 1e3:.3f} ms, scan kernels min {min(ms):.3f} med {np.median(ms):.3f} ms | {idx.last_plan()}", flush=True)
 
 
 if __name__ == "__main__":
