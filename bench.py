@@ -291,7 +291,8 @@ def main():
                        "executed_TFLOPs": round(terms * s_tf, 2), "vs_fp32_mfma_peak": round(s_tf / PEAK_F32_MFMA_TF, 3),
                        "hbm_GBps_same_kernel": round(s_gbs, 1),
                        "note": "fp16-MFMA prefilter under a proven error bound + exact fp32 rescoring (results are the fp32 results); "
-                               "achieved = algorithmic 2*nq*n*768 flop / the hipEvent bracket around both scanh launches of a search"}
+                               "achieved = algorithmic 2*nq*n*768 flop / the hipEvent bracket around all scanh launches of a search (seeding pass, threshold "
+                               "selections and up to three passes over consecutive row ranges); traffic = HBM bytes of the main passes per search"}
     elif (s_flops / s_bytes) > (PEAK_F32_MFMA_TF * 1e12) / (PEAK_HBM_GBS * 1e9):
         search_roof = {"kernel": plan.split(" ")[0], "plan": plan, "bound": "mfma", "achieved": round(s_tf, 2), "peak": PEAK_F32_MFMA_TF,
                        "unit": "TFLOP/s", "frac": round(s_tf / PEAK_F32_MFMA_TF, 4), "kernel_ms": round(scan_avg_ms, 4)}

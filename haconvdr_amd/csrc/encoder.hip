@@ -1315,6 +1315,7 @@ struct hac_encoder {
     // A/B in one process on the 1000 x 512 forward (tools/ab_encoder.py), two boxes: SPLIT -1 .. -3.4 % on FFN-down (K = 3072),
     // +-1 % (inside the run-to-run spread) on the K = 768 GEMMs; layer stack 93.4 - 94.9 ms with every class split vs 95.3 - 96.7 with none
     int g8_split = 15;
+    int g8_stagger = -1;   // -1 auto (phased workgroup starts of the K = 768 RESID / QKV classes on long tile runs), 0 off
     void *h_pin = nullptr;
     size_t h_pin_bytes = 0;
     int *h_len = nullptr;      // pinned: padded lengths of a forward that runs as several sub-batches
@@ -1523,6 +1524,17 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
         g8a.n_groups = 1;
         const int ng_up = 2;   // FFN-up: W1' is 4.7 MB against 4 MB of L2 per XCD; each XCD owns half of its column tiles (measured: -2 %)
         const dim3 grid8((unsigned)e->n_cu), blk8(512);
+        // Phased starts (Gemm8Args::stagger): workgroups that start together stay together -- every tile takes the same time --
+        // and reach their epilogues, the phases that write (and, RESID, read) the residual stream, all at once.  Delaying the
+        // XCDs by 0..3 quarter-steps at the start spreads those bursts: QKV -3.8 % and out-proj -3.5 % at 512000 rows
+        // (tools/probes/gemm8_stagger_probe.hip: 1.786 -> 1.718 ms, 0.803 -> 0.775 ms); the FFN classes did not move (their
+        // tile times are longer and already drift apart) and stay unphased.  Only on runs of >= 16 tiles per workgroup: the
+        // delay (<= 3 steps of ~1 us x stagger) is paid once per launch.
+        auto stagger8 = [&](int N, int n_tile0, int steps) {
+            const long tiles = (Mp / 256) * (long)(N / 256 - n_tile0);
+            g8a.stagger = (e->g8_stagger != 0 && tiles >= 16L * e->n_cu) ? steps : 0;
+            g8a.stagger_mode = 0;
+        };
         // gemm8.inc's two loop forms: SPLIT (operand-split DMA roles, 160 KiB) / round 2's (128 KiB); one bit of g8_split per class
         auto launch8 = [&](auto epi, int cls_bit) {
             constexpr int EPI = decltype(epi)::value;
@@ -1540,8 +1552,10 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
             g8a.W = w.wqkv8; g8a.N = 3 * H; g8a.wsum = w.fold; g8a.cvec = w.fold + 3 * H; g8a.q = q; g8a.k = k; g8a.v16 = vt;
             // last layer: keys and values of every row, queries of the <s> rows only (a third of the GEMM: 0.6 ms per 1000 x 512 forward)
             g8a.n_tile0 = last ? H / 256 : 0;
+            stagger8(3 * H, g8a.n_tile0, 6);
             launch8(epi_qkv, 0);
             g8a.n_tile0 = 0;
+            g8a.stagger = 0;
             if (last) cls_q_kernel<<<dim3((unsigned)((B + CLS_SB - 1) / CLS_SB), H / CLS_NS), dim3(256), 0, st>>>(xb, g8a.astats, s, B, w.wqkv8, w.fold, w.fold + 3 * H, q);
             HAC_TRY(prof_end(e, 1 + HAC_ENC_CLASS_QKV, st));
         } else {
@@ -1569,7 +1583,9 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
             g8a.A = ctx; g8a.W = w.wo; g8a.N = H; g8a.K = H; g8a.cvec = w.bo; g8a.resid = xb; g8a.yb = yAb; g8a.part = part;
             g8a.rstats = defer_in ? statsF : nullptr; g8a.rgamma = ln2g_prev; g8a.rbeta = ln2b_prev;
             HAC_TRY(prof_begin(e, 1 + HAC_ENC_CLASS_OUTPROJ, st));
+            stagger8(H, 0, 8);
             launch8(epi_resid, 1);
+            g8a.stagger = 0;
             HAC_TRY(prof_end(e, 1 + HAC_ENC_CLASS_OUTPROJ, st));
             HAC_TRY(prof_begin(e, 1 + HAC_ENC_CLASS_LN, st));
             ln_combine_kernel<<<dim3((unsigned)(Mp / 256)), dim3(256), 0, st>>>(part, H / 64, H, total, c.ln_eps, statsA);
@@ -2006,6 +2022,9 @@ int hac_encoder_set_option(hac_encoder *e, const char *name, const char *value) 
         const long t = strtol(value, &end, 10);
         if (end == value || *end || t < 0 || t > 15) return fail(HAC_ERR_INVALID, "encoder option g8_split = '%s': a bit mask 0..15", value);
         e->g8_split = (int)t;
+    } else if (n == "g8_stagger") {
+        if (v != "auto" && v != "off") return fail(HAC_ERR_INVALID, "encoder option g8_stagger = '%s': auto | off", value);
+        e->g8_stagger = v == "off" ? 0 : -1;
     } else if (n == "ksplit") {
         if (v != "auto" && v != "off") return fail(HAC_ERR_INVALID, "encoder option ksplit = '%s': auto | off", value);
         e->ksplit_mode = v == "off" ? 0 : -1;

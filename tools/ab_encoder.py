@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""A/B of encoder options in ONE process, interleaved rounds (cdna_hip_programming.md 5.4 rule 24): per kernel class ms of a
-1000 x 512 forward (the bench's encode leg) for each value of an option.
-  python tools/ab_encoder.py g8_split 0 15 [rounds]"""
+"""Encoder timing for A/B runs of an option: the bench's 1000 x 512 forward with option values interleaved in one process.
+  python tools/ab_encoder.py g8_stagger auto off [B] [L]"""
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -14,34 +14,32 @@ sys.path.insert(0, ROOT)
 def main():
     import torch
     from haconvdr_amd import synth
-    from haconvdr_amd.encoder import ANCEEncoder
-    name, values = sys.argv[1], sys.argv[2:]
-    rounds = 3
-    if values and values[-1].startswith("r="):
-        rounds = int(values.pop()[2:])
-    enc = ANCEEncoder.from_state_dict(synth.ance_state_dict(0xA11CE, 12, rich=False))
-    tok, _ = synth.token_batch(0x70C, 1000, 512, fixed_len=512)
-    ids = torch.from_numpy(tok.astype(np.int64)).cuda()
-    mask = torch.ones_like(ids)
-    res = {v: [] for v in values}
-    for r in range(rounds + 1):
+    from haconvdr_amd import encoder as E
+    name, values = sys.argv[1], sys.argv[2:4]
+    B = int(sys.argv[4]) if len(sys.argv) > 4 else 1000
+    Lq = int(sys.argv[5]) if len(sys.argv) > 5 else 512
+    ids, _ = synth.token_batch(5, B, Lq, fixed_len=Lq)
+    ids_t = torch.from_numpy(ids.astype(np.int64)).cuda()
+    mask_t = torch.ones_like(ids_t)
+    enc = E.ANCEEncoder.from_state_dict(synth.ance_state_dict(0xA11CE, 12, rich=False))
+    ref = None
+    best = {v: 1e9 for v in values}
+    for rnd in range(4):
         for v in values:
             enc.set_option(name, v)
-            enc.set_profiling(True, classes="all")
-            enc(ids, mask)
+            for _ in range(2):
+                out = enc(ids_t, mask_t)
             torch.cuda.synchronize()
-            stack = float(np.sum(enc.profile_drain()))
-            per = {c: float(np.sum(enc.profile_drain_class(c))) for c in enc.KERNEL_CLASSES}
-            enc.set_profiling(False)
-            if r:
-                res[v].append((stack, per))
-    for v in values:
-        st = np.array([x[0] for x in res[v]])
-        line = f"{name}={v}: stack min {st.min():.2f} med {np.median(st):.2f} ms |"
-        for c in enc.KERNEL_CLASSES:
-            a = np.array([x[1][c] for x in res[v]])
-            line += f" {c} {a.min():.2f}"
-        print(line, flush=True)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                out = enc(ids_t, mask_t)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 5
+            best[v] = min(best[v], dt)
+            if ref is None:
+                ref = out.clone()
+            print(f"round {rnd} {name}={v}: {dt * 1e3:.2f} ms  same bits as the first run: {bool(torch.equal(out, ref))}", flush=True)
+    print("best: " + ", ".join(f"{name}={v} {best[v] * 1e3:.2f} ms" for v in values), flush=True)
 
 
 if __name__ == "__main__":
