@@ -351,7 +351,9 @@ def main():
                 ent["frac_of_2.5PF"] = round(fl_step[name] / (per_step * 1e-3) / 2.5e15, 4)
             kernels.append(ent)
         if "kernel_ms" in search_roof:
-            kernels.append({"class": "search_scan", "kernel": search_roof["kernel"], "ms_per_step": search_roof["kernel_ms"], "launches_per_step": 2,
+            # scan launches inside the bracket: seeding pass + the main scan's passes (plan text), or the one exact-kernel scan
+            scan_launches = (int(plan.split("seed=")[1].split()[0]) + int(plan.split("passes=")[1].split()[0])) if "passes=" in plan else 1
+            kernels.append({"class": "search_scan", "kernel": search_roof["kernel"], "ms_per_step": search_roof["kernel_ms"], "launches_per_step": scan_launches,
                             "share_of_step": round(search_roof["kernel_ms"] / ms_per_step, 3),
                             ("frac_of_2.5PF" if search_roof["bound"] == "mfma" and search_roof["peak"] == PEAK_F16_MFMA_TF else "frac"): search_roof["frac"]})
         resid = sum(e["ms_per_step"] for e in kernels if e["class"] in ("out_proj", "ffn_down"))

@@ -973,13 +973,26 @@ struct DeviceIndex {
         int split_decide = -1;           // who reads the certificates: -1 by entry point (host API: host, *_device: device), 0 host, 1 device
         int debug_max_pass = 0;          // tests: pass bound of the candidate loops (0 = the kernels' own, which no legal input reaches)
         int scan_passes = 0;             // prefilter scan: 0 by size, 1..3 pins the number of passes (threshold refreshes between them)
+        int pass_cut[2] = {0, 0};        // where the passes end, in thousandths of the row groups (option "scan_pass_cuts" = "a,b"); 0 = by size
     } tune;
-    // passes of the prefilter's main scan (search_keys_split): a refresh costs a kernel tail + a selection (~0.1 ms), so only
-    // scans of several milliseconds are cut, and only with seeded thresholds (the refresh raises them in place)
-    int scan_passes(u32 G, u32 round_groups, bool seeded) const {
+    // Passes of the prefilter's main scan (search_keys_split) and where they end (row groups, whole rounds).  A refresh costs a
+    // kernel tail + a selection (~0.1 ms): only scans of a few milliseconds are cut, and only with seeded thresholds (the refresh
+    // raises them in place).  Measured optimum over 2M .. 25M rows (tools/ab_search.py sweeps, round 4): a SHORT seeding pass (1024
+    // groups: its only job is to keep the first pass's lists from overflowing), the first cut after ~6k groups, the second at the
+    // geometric mean of the first and the corpus -- 25M rows: 1.6 % / 12.5 %, 4M: 10 % / 31 %.  Below ~1.5M rows one pass is faster.
+    int scan_passes(u32 G, u32 round_groups, bool seeded, u32 bounds[4]) const {
+        bounds[0] = 0u;
+        bounds[1] = bounds[2] = bounds[3] = G;
         if (!seeded) return 1;
-        int n = tune.scan_passes > 0 ? tune.scan_passes : (G >= 98304u ? 3 : (G >= 49152u ? 2 : 1));   // >= 6.3M / 3.1M rows
-        while (n > 1 && (u32)(0.08 * G) / round_groups == 0) --n;
+        int n = tune.scan_passes > 0 ? tune.scan_passes : (G >= 24576u ? 3 : 1);
+        if (n >= 2) {
+            const double c1 = tune.pass_cut[0] ? tune.pass_cut[0] * 1e-3 * G : std::max(6144.0, 0.015 * G);
+            const double c2 = tune.pass_cut[1] ? tune.pass_cut[1] * 1e-3 * G : std::sqrt(c1 * (double)G);
+            bounds[1] = (u32)(c1 / round_groups + 0.5) * round_groups;
+            if (n >= 3) bounds[2] = (u32)(c2 / round_groups + 0.5) * round_groups;
+            if (n >= 3 && !(bounds[1] < bounds[2] && bounds[2] < G)) n = 2, bounds[2] = G;   // (small corpora with a pinned pass count)
+            if (!(0u < bounds[1] && bounds[1] < G)) n = 1, bounds[1] = bounds[2] = G;
+        }
         return n;
     }
     void read_env() {
@@ -1023,6 +1036,12 @@ struct DeviceIndex {
         } else if (n == "split_decide") {
             if (!one_of({"auto", "host", "device"})) return HAC_ERR_INVALID;
             tune.split_decide = v == "host" ? 0 : (v == "device" ? 1 : -1);
+        } else if (n == "scan_pass_cuts") {
+            int a = 0, b = 0;
+            if (v == "auto") a = b = 0;
+            else if (sscanf(v.c_str(), "%d,%d", &a, &b) != 2 || a < 1 || b <= a || b > 900) return HAC_ERR_INVALID;
+            tune.pass_cut[0] = a;
+            tune.pass_cut[1] = b;
         } else if (n == "scan_passes") {
             if (!one_of({"auto", "1", "2", "3"})) return HAC_ERR_INVALID;
             tune.scan_passes = v == "auto" ? 0 : atoi(v.c_str());
@@ -1696,7 +1715,7 @@ struct DeviceIndex {
         sp.K2 = K2;
         sp.thr_is_approx = 1;
         long P_last = 0;
-        int n_qtiles_last = 0, seeded = 0, n_chunks = 0;
+        int n_qtiles_last = 0, seeded = 0, n_chunks = 0, passes_last = 1;
         for (int64_t off = 0; off < nq; off += chunk, ++n_chunks) {
             const int64_t n = std::min<int64_t>(chunk, nq - off);
             const float *qc = q_dev + (size_t)off * d;
@@ -1734,7 +1753,10 @@ struct DeviceIndex {
             // a sixteenth of 25M rows cost 1.5 ms more per 1000-query search, 2k groups 11 ms more).
             const dim3 grid((unsigned)P, (unsigned)n_qtiles), blk(SH_W * 64);
             const u32 round_groups = (u32)P * SH_GPR;
-            const u32 seed_cap = tune.seed_groups_max > 0 ? (u32)tune.seed_groups_max : (u32)(14.0 * std::sqrt((double)G));
+            // (a scan that will be cut into passes refreshes its thresholds after ~6k groups anyway: 1024 groups of seeding do)
+            u32 probe_bounds[4];
+            const bool multipass = scan_passes(G, round_groups, true, probe_bounds) > 1;
+            const u32 seed_cap = tune.seed_groups_max > 0 ? (u32)tune.seed_groups_max : multipass ? 1024u : (u32)(14.0 * std::sqrt((double)G));
             u32 GA = std::min<u32>(G, (std::max<u32>(std::min<u32>(G / 16u, seed_cap), 768u) + round_groups - 1u) / round_groups * round_groups);
             const float *thr_init = nullptr;
             if ((size_t)4 * GA >= (size_t)K2) {
@@ -1756,12 +1778,8 @@ struct DeviceIndex {
             // do, and parking + appending those candidates is ~12 % of the kernel.  Between passes the K2-th best s~ of everything
             // found SO FAR (all row streams together: select_keys_kernel over the survivors flushed by the passes before) is a
             // valid, much sharper bound: after 8 % of the rows ~3x fewer pairs pass, after 30 % ~8x fewer.
-            const int n_pass = scan_passes(G, round_groups, thr_init != nullptr);
-            u32 bounds[4] = {0u, 0u, 0u, G};
-            if (n_pass >= 2) bounds[1] = (u32)(0.08 * G) / round_groups * round_groups;
-            if (n_pass >= 3) bounds[2] = (u32)(0.30 * G) / round_groups * round_groups;
-            if (n_pass == 2) bounds[2] = G;
-            if (n_pass == 1) bounds[1] = bounds[2] = G;
+            u32 bounds[4];
+            const int n_pass = scan_passes(G, round_groups, thr_init != nullptr, bounds);
             a.thr_init = thr_init;
             for (int ps = 0; ps < n_pass; ++ps) {
                 a.g_first = bounds[ps];
@@ -1777,6 +1795,7 @@ struct DeviceIndex {
                 }
             }
             a.g_first = 0;
+            passes_last = n_pass;
             if (profiling) {
                 HAC_HIP(hipEventRecord(ev_pool[ev_used].second, st));
                 ++ev_used;
@@ -1829,8 +1848,8 @@ struct DeviceIndex {
                                                                                                   (int)nq, k, keys_out, nf_dev);
             HAC_HIP(hipGetLastError());
             ++split_searches;
-            snprintf(plan_head, sizeof plan_head, "split: scanh_kernel<%d> grid=(%ld,%d) NQ=%d K2=%d chunks=%d lds=%zu seed=%d", terms, P_last,
-                     n_qtiles_last, SH_NQ, K2, n_chunks, lds, seeded);
+            snprintf(plan_head, sizeof plan_head, "split: scanh_kernel<%d> grid=(%ld,%d) NQ=%d K2=%d chunks=%d lds=%zu seed=%d passes=%d", terms, P_last,
+                     n_qtiles_last, SH_NQ, K2, n_chunks, lds, seeded, passes_last);
             snprintf(last_plan, sizeof last_plan, "%s fallback=device-side/%lld", plan_head, (long long)nq);
             HAC_HIP(hipMemcpyAsync(h_plan, ws_stat.p, 8, hipMemcpyDeviceToHost, st));
             HAC_HIP(hipEventRecord(ev_plan, st));
@@ -1845,8 +1864,8 @@ struct DeviceIndex {
         std::memcpy(&maxratio, &h_fb[1], 4);
         if (level == 0) ++split_searches;
         char plan_here[sizeof last_plan];
-        snprintf(plan_here, sizeof plan_here, "split: scanh_kernel<%d> grid=(%ld,%d) NQ=%d K2=%d chunks=%d lds=%zu seed=%d fallback=%u/%lld err/bound=%.3g",
-                 terms, P_last, n_qtiles_last, SH_NQ, K2, n_chunks, lds, seeded, nfail, (long long)nq, (double)maxratio);
+        snprintf(plan_here, sizeof plan_here, "split: scanh_kernel<%d> grid=(%ld,%d) NQ=%d K2=%d chunks=%d lds=%zu seed=%d passes=%d fallback=%u/%lld err/bound=%.3g",
+                 terms, P_last, n_qtiles_last, SH_NQ, K2, n_chunks, lds, seeded, passes_last, nfail, (long long)nq, (double)maxratio);
         std::memcpy(last_plan, plan_here, sizeof last_plan);
         plan_pending = false;
         if (nfail == 0) return HAC_OK;

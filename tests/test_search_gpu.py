@@ -1083,6 +1083,8 @@ def test_auto_mode_answers_with_the_exact_kernels_when_the_fp16_image_does_not_f
     idx.add_tensor(x)
     D0, I0 = idx.search_tensor(q[:8], k)                       # few queries: exact kernels, sizes the small workspaces
     torch.cuda.synchronize()
+    import gc
+    gc.collect()                                               # indexes of earlier tests that are still waiting for the collector
     torch.cuda.empty_cache()                                   # the hog must come out of DEVICE memory, not out of torch's cache
     free, _ = torch.cuda.mem_get_info()
     hog = torch.empty(max(0, free - (700 << 20)), dtype=torch.uint8, device="cuda")    # 1.5 GB of image no longer fit

@@ -3,6 +3,7 @@
 //   B  packed fp16: clamp, round-to-integer by the 1.5 * 2^10 magic add, f = x - n, cubic 2^f, scale 2^n built by a 16-bit shift/add, multiply
 //      (two elements per instruction; P is rounded to bf16 behind it anyway)
 //   C  as B with a quadratic 2^f (max relative error 1.8e-3, about bf16's own rounding)
+//   D / E / F  the plain rates: v_pk_fma_f32, v_pk_fma_f16 (pairs), v_fma_f32 -- is there a cheaper arithmetic for the epilogues?
 // Each variant runs 16 independent chains per lane inside a long loop, 4 waves per SIMD, every CU: elements per cycle and SIMD from
 // the wall clock and s_memtime-free arithmetic (clock from the A run's known issue rate is not assumed: the table prints ns per element-wave).
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/probes/exp_rate_probe.hip -o scratch/exp_rate
@@ -59,6 +60,56 @@ template <int MODE> __global__ __launch_bounds__(256) void rate_kernel(float *ou
     if (acc == 12345.678f) out[0] = acc;   // never true: keeps the chains alive
 }
 
+// D / E: what a packed fma costs -- v_pk_fma_f32 (two fp32 per lane and instruction) against v_pk_fma_f16, 8 independent chains of pairs
+typedef float f2 __attribute__((ext_vector_type(2)));
+template <int MODE> __global__ __launch_bounds__(256) void fma_kernel(float *out, int iters, float seed) {
+    float acc = 0.f;
+    if (MODE == 0) {
+        f2 v[8];
+        const f2 a = {0.999f, 0.998f}, b = {seed, -seed};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = f2{seed * (float)(i + 1), (float)(threadIdx.x & 7)};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = __builtin_elementwise_fma(v[i], a, b);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc += v[i].x + v[i].y;
+    } else if (MODE == 1) {
+        h2 v[8];
+        const h2 a = {(_Float16)0.999f, (_Float16)0.998f}, b = {(_Float16)seed, (_Float16)-seed};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = h2{(_Float16)(seed * (float)(i + 1)), (_Float16)(float)(threadIdx.x & 7)};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = __builtin_elementwise_fma(v[i], a, b);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc += (float)v[i].x + (float)v[i].y;
+    } else {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = seed * (float)(i + 1) + (float)(threadIdx.x & 7);
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = fmaf(v[i], 0.999f, seed);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc += v[i];
+    }
+    if (acc == 12345.678f) out[0] = acc;
+}
+template <int MODE> float run_fma(float *out, int iters) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    fma_kernel<MODE><<<256 * 4, 256>>>(out, iters, 0.001f); CK(hipDeviceSynchronize());
+    float best = 1e9f;
+    for (int r = 0; r < 3; ++r) {
+        CK(hipEventRecord(e0)); fma_kernel<MODE><<<256 * 4, 256>>>(out, iters, 0.001f); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = ms < best ? ms : best;
+    }
+    return best;
+}
+
 // accuracy of the packed forms against exp2f over [-16, 0]
 __global__ void acc_kernel(float *err) {
     float e3 = 0.f, e2 = 0.f, a3 = 0.f, a2 = 0.f;
@@ -93,6 +144,16 @@ int main() {
     for (int m = 0; m < 3; ++m) {
         const double wave_elems = (double)iters * 16, ns_per_wave_elem = ms[m] * 1e6 / (wave_elems * 4);   // per SIMD: 4 waves in sequence on one VALU
         printf("%-42s %.3f ms: %.3f ns per wave-wide element on a SIMD (= %.1f cycles at 2.4 GHz)\n", names[m], ms[m], ns_per_wave_elem, ns_per_wave_elem * 2.4);
+    }
+    {
+        const char *fn[3] = {"D v_pk_fma_f32 (8 pairs per lane and iteration)", "E v_pk_fma_f16 (8 pairs per lane and iteration)", "F v_fma_f32 (16 per lane and iteration)"};
+        float fm[3] = {run_fma<0>(out, iters), run_fma<1>(out, iters), run_fma<2>(out, iters)};
+        const int instr[3] = {8, 8, 16};
+        for (int m = 0; m < 3; ++m) {
+            const double ns_per_instr = fm[m] * 1e6 / ((double)iters * instr[m] * 4);
+            printf("%-50s %.3f ms: %.3f ns per wave instruction on a SIMD (= %.1f cycles at 2.4 GHz), %.1f cycles per element\n", fn[m], fm[m], ns_per_instr,
+                   ns_per_instr * 2.4, ns_per_instr * 2.4 * instr[m] / 16);
+        }
     }
     acc_kernel<<<1, 256>>>(out + 4); CK(hipDeviceSynchronize());
     float h[4]; CK(hipMemcpy(h, out + 4, 16, hipMemcpyDeviceToHost));
