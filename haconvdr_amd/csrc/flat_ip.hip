@@ -972,26 +972,36 @@ struct DeviceIndex {
         int seed_groups_max = 0;         // cap of the seeding pass of the prefilter scan, in 64-row groups; 0 = 14 sqrt(groups)
         int split_decide = -1;           // who reads the certificates: -1 by entry point (host API: host, *_device: device), 0 host, 1 device
         int debug_max_pass = 0;          // tests: pass bound of the candidate loops (0 = the kernels' own, which no legal input reaches)
-        int scan_passes = 0;             // prefilter scan: 0 by size, 1..3 pins the number of passes (threshold refreshes between them)
+        int scan_passes = 0;             // prefilter scan: 0 by size, 1..5 pins the number of passes (threshold refreshes between them)
         int pass_cut[2] = {0, 0};        // where the passes end, in thousandths of the row groups (option "scan_pass_cuts" = "a,b"); 0 = by size
     } tune;
     // Passes of the prefilter's main scan (search_keys_split) and where they end (row groups, whole rounds).  A refresh costs a
     // kernel tail + a selection (~0.1 ms): only scans of a few milliseconds are cut, and only with seeded thresholds (the refresh
     // raises them in place).  Measured optimum over 2M .. 25M rows (tools/ab_search.py sweeps, round 4): a SHORT seeding pass (1024
     // groups: its only job is to keep the first pass's lists from overflowing), the first cut after ~6k groups, the second at the
-    // geometric mean of the first and the corpus -- 25M rows: 1.6 % / 12.5 %, 4M: 10 % / 31 %.  Below ~1.5M rows one pass is faster.
-    int scan_passes(u32 G, u32 round_groups, bool seeded, u32 bounds[4]) const {
+    // geometric mean of the first and the corpus (4M rows: 10 % / 31 %); a fourth pass is worth another 0.05 ms from ~8M rows
+    // (25M: cuts at 1.6 % / 6.3 % / 25 %), a fifth nothing.  Below ~1.5M rows one pass is faster.
+    static constexpr int MAX_PASSES = 5;
+    int scan_passes(u32 G, u32 round_groups, bool seeded, u32 bounds[MAX_PASSES + 1]) const {
         bounds[0] = 0u;
-        bounds[1] = bounds[2] = bounds[3] = G;
+        for (int i = 1; i <= MAX_PASSES; ++i) bounds[i] = G;
         if (!seeded) return 1;
-        int n = tune.scan_passes > 0 ? tune.scan_passes : (G >= 24576u ? 3 : 1);
+        int n = tune.scan_passes > 0 ? tune.scan_passes : (G >= 131072u ? 4 : G >= 24576u ? 3 : 1);   // from 8.4M / 1.6M rows
         if (n >= 2) {
+            // cuts c_1 .. c_{n-1} in geometric progression from c_1 towards G (n = 3 with the option's explicit second cut: that one)
             const double c1 = tune.pass_cut[0] ? tune.pass_cut[0] * 1e-3 * G : std::max(6144.0, 0.015 * G);
-            const double c2 = tune.pass_cut[1] ? tune.pass_cut[1] * 1e-3 * G : std::sqrt(c1 * (double)G);
-            bounds[1] = (u32)(c1 / round_groups + 0.5) * round_groups;
-            if (n >= 3) bounds[2] = (u32)(c2 / round_groups + 0.5) * round_groups;
-            if (n >= 3 && !(bounds[1] < bounds[2] && bounds[2] < G)) n = 2, bounds[2] = G;   // (small corpora with a pinned pass count)
-            if (!(0u < bounds[1] && bounds[1] < G)) n = 1, bounds[1] = bounds[2] = G;
+            const double ratio = std::pow((double)G / c1, 1.0 / (n - 1));
+            double c = c1;
+            for (int i = 1; i < n; ++i, c *= ratio) {
+                const double ci = (i == 2 && n == 3 && tune.pass_cut[1]) ? tune.pass_cut[1] * 1e-3 * G : c;
+                bounds[i] = (u32)(ci / round_groups + 0.5) * round_groups;
+            }
+            bool ok = true;
+            for (int i = 1; i < n; ++i) ok = ok && bounds[i - 1] < bounds[i] && bounds[i] < G;
+            if (!ok) {   // (small corpora with a pinned pass count)
+                n = 1;
+                for (int i = 1; i <= MAX_PASSES; ++i) bounds[i] = G;
+            }
         }
         return n;
     }
@@ -1043,7 +1053,7 @@ struct DeviceIndex {
             tune.pass_cut[0] = a;
             tune.pass_cut[1] = b;
         } else if (n == "scan_passes") {
-            if (!one_of({"auto", "1", "2", "3"})) return HAC_ERR_INVALID;
+            if (!one_of({"auto", "1", "2", "3", "4", "5"})) return HAC_ERR_INVALID;
             tune.scan_passes = v == "auto" ? 0 : atoi(v.c_str());
         } else if (n == "debug_max_pass") {
             char *end = nullptr;
@@ -1686,7 +1696,8 @@ struct DeviceIndex {
         HAC_TRY(ws_qsplit.reserve((size_t)n_qtiles_max * SH_NQ * d * 2 * (terms == 3 ? 2 : 1)));
         HAC_TRY(ws_delta.reserve((size_t)(nq + SH_NQ) * 4));
         HAC_TRY(ws_cand.reserve((size_t)Pmax * SH_NQ * C2 * 8));          // P * n_qtiles <= n_cu workgroups
-        HAC_TRY(ws_partial.reserve((size_t)chunk * Pmax * K2 * 8 * 3));
+        // (n queries of a chunk in ceil(n / SH_NQ) tiles with P <= n_cu / tiles row streams each: n * P <= SH_NQ * n_cu)
+        HAC_TRY(ws_partial.reserve((size_t)std::min<int64_t>(chunk, SH_NQ) * Pmax * K2 * 8 * MAX_PASSES));
         HAC_TRY(ws_pcnt.reserve((size_t)chunk * 4));
         HAC_TRY(ws_thrglob.reserve(((size_t)n_qtiles_max * SH_NQ + THR_CTL_WORDS) * 4));
         HAC_TRY(ws_akeys.reserve((size_t)nq * K2 * 8));
@@ -1724,7 +1735,7 @@ struct DeviceIndex {
             long P = std::max<long>(1, n_cu / n_qtiles);
             if (P >= 8) P = P / 8 * 8;  // same-row workgroups of different query tiles share an XCD (L2)
             P = std::max<long>(1, std::min<long>(P, (G + SH_GPR - 1) / SH_GPR));
-            const long pstride = (long)P * K2 * 3;   // a workgroup flushes at most K2 survivors per query and pass: up to three passes
+            const long pstride = (long)P * K2 * MAX_PASSES;   // a workgroup flushes at most K2 survivors per query and pass
             float *delta_c = (float *)ws_delta.p + off;
             u64 *akeys_c = (u64 *)ws_akeys.p + (size_t)off * K2;
             split_queries_kernel<<<dim3((unsigned)nq_pad), dim3(192), 0, st>>>(reinterpret_cast<const float4 *>(qc), (int)n, K4, terms,
@@ -1754,7 +1765,7 @@ struct DeviceIndex {
             const dim3 grid((unsigned)P, (unsigned)n_qtiles), blk(SH_W * 64);
             const u32 round_groups = (u32)P * SH_GPR;
             // (a scan that will be cut into passes refreshes its thresholds after ~6k groups anyway: 1024 groups of seeding do)
-            u32 probe_bounds[4];
+            u32 probe_bounds[MAX_PASSES + 1];
             const bool multipass = scan_passes(G, round_groups, true, probe_bounds) > 1;
             const u32 seed_cap = tune.seed_groups_max > 0 ? (u32)tune.seed_groups_max : multipass ? 1024u : (u32)(14.0 * std::sqrt((double)G));
             u32 GA = std::min<u32>(G, (std::max<u32>(std::min<u32>(G / 16u, seed_cap), 768u) + round_groups - 1u) / round_groups * round_groups);
@@ -1778,7 +1789,7 @@ struct DeviceIndex {
             // do, and parking + appending those candidates is ~12 % of the kernel.  Between passes the K2-th best s~ of everything
             // found SO FAR (all row streams together: select_keys_kernel over the survivors flushed by the passes before) is a
             // valid, much sharper bound: after 8 % of the rows ~3x fewer pairs pass, after 30 % ~8x fewer.
-            u32 bounds[4];
+            u32 bounds[MAX_PASSES + 1];
             const int n_pass = scan_passes(G, round_groups, thr_init != nullptr, bounds);
             a.thr_init = thr_init;
             for (int ps = 0; ps < n_pass; ++ps) {

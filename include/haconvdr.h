@@ -137,9 +137,9 @@ int hac_index_last_status(hac_index *idx);
  * "seed_groups_max" = cap of the prefilter's seeding pass in 64-row groups (integer >= 0; 0 = by size: 14 sqrt(groups),
  * or 1024 groups when the scan is cut into passes),
  * "split_decide" = "auto" (host entry point: host, *_device: device) | "host" | "device": who reads the certificates,
- * "scan_passes" = "auto" | "1" | "2" | "3" (prefilter: passes of the main scan, the thresholds refreshed from everything found so
- * far between them; auto: 3 from 1.6M rows), "scan_pass_cuts" = "auto" | "a,b" (where the passes end, in thousandths of the rows;
- * auto: after ~6k 64-row groups and at the geometric mean of that and the corpus), "debug_max_pass" = integer >= 0 (tests: the pass bound of the
+ * "scan_passes" = "auto" | "1" .. "5" (prefilter: passes of the main scan, the thresholds refreshed from everything found so
+ * far between them; auto: 3 from 1.6M rows, 4 from 8.4M), "scan_pass_cuts" = "auto" | "a,b" (where the first two passes end, in
+ * thousandths of the rows; auto: the first after ~6k 64-row groups, the others in geometric progression towards the corpus), "debug_max_pass" = integer >= 0 (tests: the pass bound of the
  * candidate loops; 0 = the bound no legal input reaches).
  * Any other name or value is HAC_ERR_INVALID (never a silent default).
  * The HAC_<NAME> environment variables give the defaults and are read once, in hac_index_create. */
