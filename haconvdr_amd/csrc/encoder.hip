@@ -1120,6 +1120,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void attention_stream_kernel(AttnArg
                     const u32x4 ov = {pe[0], pe[1], po[0], po[1]};
                     // s_nop: a store of more than 64 bits may not be followed at once by a VALU write of its data registers
                     // (hipcc's hazard recognizer inserts the wait states for its own stores; it cannot see into this one)
+                    // (temporal on purpose: with the nt bit the out-projection behind it misses what it finds cached today, +0.6 ms per forward)
                     asm volatile("global_store_dwordx4 %0, %1, off offset:%2\n\ts_nop 1" ::"v"(crow), "v"(ov), "n"((32 * tt + 16 * j) * 2) : "memory");
                 }
         }
