@@ -43,9 +43,12 @@ int main(){
   const int staggers[] = {0, 2, 4, 6, 8, 12, 16, 24};
   for(auto&c: cfgs){
     g.N=c.N; g.K=c.K; g.n_groups = c.epi==EPI8_GELU ? 2 : 1;
-    if (getenv("G8_BASE_ONLY")) {   // one figure per class (A/B of build flags: G8_NT_STORE, G8_NT_A)
-      g.stagger = 0; float best = 1e9f; for (int r = 0; r < 5; ++r) best = std::min(best, run(g, c.epi, 4));
-      printf("%s %s: %.3f ms %4.0f TF\n", getenv("G8_BASE_ONLY"), c.name, best, 2.0*M*c.N*c.K/best/1e9); fflush(stdout);
+    if (getenv("G8_BASE_ONLY")) {   // one figure per class and column-group count (A/B of build flags, e.g. -DG8_NT_EPIS=0)
+      for (int ng : {1, 2, 4}) {
+        if ((c.N / 256) % ng) continue;
+        g.n_groups = ng; g.stagger = 0; float best = 1e9f; for (int r = 0; r < 5; ++r) best = std::min(best, run(g, c.epi, 4));
+        printf("%s %s n_groups %d: %.3f ms %4.0f TF\n", getenv("G8_BASE_ONLY"), c.name, ng, best, 2.0*M*c.N*c.K/best/1e9); fflush(stdout);
+      }
       continue;
     }
     for (int mode = 0; mode < 4; ++mode) {
