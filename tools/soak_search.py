@@ -9,7 +9,7 @@ import torch
 from haconvdr_amd.index import FlatIPIndex
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 240.0
-t0 = time.time(); n_cases = 0; n_split = 0
+t0 = time.time(); n_cases = 0; n_split = 0; n_multi = 0
 while time.time() - t0 < budget:
     n = int(rng.choice([20_000, 50_001, 130_000, 400_000, 1_000_000]))
     nq = int(rng.choice([1, 40, 130, 257, 1000, 1500]))
@@ -37,9 +37,17 @@ while time.time() - t0 < budget:
             qr *= 1000.0
         qsets.append(qr)
     idxs = {}
+    # the scan's pass policy (round 4) pinned at random: corpora this small take one pass by themselves
+    passes = str(rng.choice(["auto", "2", "3", "4", "5"]))
+    cuts = str(rng.choice(["auto", "100,400", "50,120", "300,600"]))
+    seed_groups = str(rng.choice(["0", "768", "4096"]))
     for split in ("1", "0"):
         idx = FlatIPIndex(768)
         idx.set_option("split", split)
+        if split == "1":
+            idx.set_option("scan_passes", passes)
+            idx.set_option("scan_pass_cuts", cuts)
+            idx.set_option("seed_groups_max", seed_groups)
         for i in range(0, n, 250_000):
             idx.add_tensor(x[i:i + 250_000])
         idxs[split] = idx
@@ -56,11 +64,12 @@ while time.time() - t0 < budget:
         ok = ok and same
         if not same:
             bad = (res[0][1] != res[1][1]).nonzero()
-            print("MISMATCH", n, qr.shape[0], k, kind, bad[:5].tolist(), res[0][2], flush=True)
+            print("MISMATCH", n, qr.shape[0], k, kind, passes, cuts, seed_groups, bad[:5].tolist(), res[0][2], flush=True)
             sys.exit(1)
     del idxs
     n_cases += 1
     if n_cases % 5 == 0:
         print(f'{n_cases} cases ok, {time.time() - t0:.0f} s', flush=True)
     n_split += res[0][2].startswith("split:")
-print(f"soak ok: {n_cases} cases ({n_split} through the prefilter) in {time.time() - t0:.0f} s", flush=True)
+    n_multi += res[0][2].startswith("split:") and "passes=1 " not in res[0][2]
+print(f"soak ok: {n_cases} cases ({n_split} through the prefilter, {n_multi} of them in several passes) in {time.time() - t0:.0f} s", flush=True)
