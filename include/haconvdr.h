@@ -55,7 +55,7 @@ typedef enum {
 /* ------------------------------------------------------------------ errors */
 /* Message of the last failing call on this thread ("" if none).  Never NULL. */
 const char *hac_last_error(void);
-/* Library version string, e.g. "haconvdr-amd 0.3.0 (gfx950)". */
+/* Library version string, e.g. "haconvdr-amd 0.4.0 (gfx950)". */
 const char *hac_version(void);
 
 /* ------------------------------------------------------------------- index */
