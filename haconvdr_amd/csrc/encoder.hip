@@ -1350,6 +1350,7 @@ struct hac_encoder {
         int seen = 0;                     // eager passes so far (the first call sizes the workspaces)
         const char *gemm = "none";
         long rows = 0;
+        int ks_out = 1, ks_down = 1;      // the plan of the captured forward (a replay runs no host-side planning)
     };
     std::map<uint64_t, GraphEntry> graphs;
     GrowBuf ws_gids, ws_gmask, ws_gout;
@@ -1704,6 +1705,8 @@ int forward_graph(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, f
         ge.seen = 1;
         ge.gemm = e->plan_gemm;
         ge.rows = e->plan_rows;
+        ge.ks_out = e->plan_ks_out;
+        ge.ks_down = e->plan_ks_down;
         e->plan_sub_batches = 1;
         e->plan_graph = "eager-first";
     } else {
@@ -1725,10 +1728,14 @@ int forward_graph(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, f
             ge.sig = ws_signature(e);
             ge.gemm = e->plan_gemm;
             ge.rows = e->plan_rows;
+            ge.ks_out = e->plan_ks_out;
+            ge.ks_down = e->plan_ks_down;
         }
         HAC_HIP(hipGraphLaunch(ge.exec, st));
         e->plan_gemm = ge.gemm;
         e->plan_rows = ge.rows;
+        e->plan_ks_out = ge.ks_out;
+        e->plan_ks_down = ge.ks_down;
         e->plan_graph = "replay";
     }
     HAC_HIP(hipMemcpyAsync(out_dev, gout, n_out, hipMemcpyDeviceToDevice, st));

@@ -1800,7 +1800,7 @@ struct DeviceIndex {
                 HAC_HIP(hipGetLastError());
                 if (ps + 1 < n_pass) {   // refresh: ws_thr[q] = max(ws_thr[q], K2-th best s~ so far)
                     select_keys_kernel<<<dim3((unsigned)n), dim3(256), (size_t)K2 * 8, st>>>((const u64 *)ws_partial.p, (size_t)pstride,
-                                                                                             (const u32 *)ws_pcnt.p, (u32)pstride, K2, K2, akeys_c, (float *)ws_thr.p,
+                                                                                             (const u32 *)ws_pcnt.p, (u32)pstride, K2, K2, nullptr, (float *)ws_thr.p,
                                                                                              nullptr, 0, 0, 1, nullptr, nullptr, true);
                     HAC_HIP(hipGetLastError());
                 }
