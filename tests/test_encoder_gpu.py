@@ -495,17 +495,21 @@ def test_options_outside_the_documented_set_are_errors():
     from haconvdr_amd._lib import HacError
     from haconvdr_amd.index import FlatIPIndex
     enc = encoder(2)
-    for name, value in (("gemm", "8-phase"), ("gemm", ""), ("attn", "two-pass"), ("max_tokens", "12"), ("max_tokens", "lots"), ("nope", "1")):
+    for name, value in (("gemm", "8-phase"), ("gemm", ""), ("attn", "two-pass"), ("max_tokens", "12"), ("max_tokens", "lots"), ("nope", "1"),
+                        ("graph", "maybe"), ("ksplit", "2"), ("g8_stagger", "on")):
         with pytest.raises(HacError):
             enc.set_option(name, value)
-    enc.set_option("gemm", "auto")
-    enc.set_option("attn", "stream")
+    for name, value in (("gemm", "auto"), ("attn", "stream"), ("graph", "off"), ("graph", "auto"), ("ksplit", "off"), ("ksplit", "auto"),
+                        ("g8_stagger", "off"), ("g8_stagger", "auto")):
+        enc.set_option(name, value)
     idx = FlatIPIndex(768)
     for name, value in (("split", "on"), ("split_terms", "2"), ("force_scan16", "yes"), ("scanq_nt", "5"), ("scanq_waves", "6"),
-                        ("scan_no_p8", "2"), ("seed_groups_max", "-3"), ("seed_groups_max", "many"), ("nope", "1")):
+                        ("scan_no_p8", "2"), ("seed_groups_max", "-3"), ("seed_groups_max", "many"), ("nope", "1"),
+                        ("scan_passes", "0"), ("scan_passes", "6"), ("scan_pass_cuts", "900,100"), ("scan_pass_cuts", "30"), ("scan_pass_cuts", "0,500")):
         with pytest.raises(HacError):
             idx.set_option(name, value)
-    for name, value in (("split", "auto"), ("split_terms", "1"), ("scanq_nt", "0"), ("scanq_waves", "8"), ("seed_groups_max", "0")):
+    for name, value in (("split", "auto"), ("split_terms", "1"), ("scanq_nt", "0"), ("scanq_waves", "8"), ("seed_groups_max", "0"),
+                        ("scan_passes", "5"), ("scan_passes", "auto"), ("scan_pass_cuts", "30,200"), ("scan_pass_cuts", "auto")):
         idx.set_option(name, value)
 
 

@@ -1117,3 +1117,47 @@ def test_auto_mode_answers_with_the_exact_kernels_when_the_fp16_image_does_not_f
     assert_same(D3[sel].cpu().numpy(), I3[sel].cpu().numpy(), oD, oI)
     oD1, oI1 = oracle.flat_ip_search(xa[:n], q[sel].cpu().numpy(), k)
     assert_same(D[sel].cpu().numpy(), I[sel].cpu().numpy(), oD1, oI1)
+
+
+@pytest.mark.gpu
+def test_pass_policy_never_changes_results(oracle):
+    """Round 4: the prefilter's main scan runs in several passes over consecutive row ranges, the thresholds refreshed in between
+    from everything found so far (and behind a much shorter seeding pass).  Whatever the number of passes, the cut points and the
+    seeding length: the same bits as the exact fp32 kernels, and the plan says what ran."""
+    import torch
+    from haconvdr_amd.index import FlatIPIndex
+    g = torch.Generator(device="cuda").manual_seed(20264)
+    n, nq, k = 2_000_003, 300, 50
+    idx, ex = FlatIPIndex(768), FlatIPIndex(768)
+    ex.set_option("split", "0")
+    for lo in range(0, n, 500_000):
+        m = min(500_000, n - lo)
+        x = torch.randn((m, 768), generator=g, device="cuda") * (1.0 + 0.5 * lo / n)    # later rows score higher: every pass raises the bar
+        idx.add_tensor(x)
+        ex.add_tensor(x)
+        if lo == 0:
+            x_head = x[:4096].cpu().numpy()
+    q = torch.randn((nq, 768), generator=g, device="cuda")
+    D0, I0 = ex.search_tensor(q, k)
+    torch.cuda.synchronize()
+    assert ex.last_plan().startswith("scanq_kernel")
+    seen = set()
+    for passes, cuts, seed in (("auto", "auto", "0"), ("1", "auto", "0"), ("2", "auto", "768"), ("3", "30,200", "0"), ("4", "auto", "4096"),
+                               ("5", "auto", "0"), ("3", "500,800", "768")):
+        idx.set_option("scan_passes", passes)
+        idx.set_option("scan_pass_cuts", cuts)
+        idx.set_option("seed_groups_max", seed)
+        D, I = idx.search_tensor(q, k)
+        torch.cuda.synchronize()
+        idx.check_status()
+        plan = idx.last_plan()
+        assert plan.startswith("split:") and "fallback=0/" in plan, plan
+        seen.add(int(plan.split("passes=")[1].split()[0]))
+        assert torch.equal(I, I0) and torch.equal(D, D0), (passes, cuts, seed, plan)
+    assert seen == {1, 2, 3, 4, 5}, seen
+    # (and the exact kernels are themselves the oracle's results on a slice the oracle finishes quickly)
+    small = FlatIPIndex(768)
+    small.add(x_head)
+    oD, oI = oracle.flat_ip_search(x_head, q[:4].cpu().numpy(), k)
+    sD, sI = small.search(q[:4].cpu().numpy(), k)
+    assert_same(sD, sI, oD, oI)
