@@ -663,6 +663,8 @@ struct AttnArgs {
     bf16 *ctx;           // [Mp][768]
     SeqInfo s;
     int cls_only;        // last layer: only the query block holding <s> is needed (models.py:56 takes [:,0])
+    int qsplit;          // streaming kernel, small batches: an item's query rows are dealt to this many workgroups (1, 2, 4, 8 or 16), see there
+    int one_class;       // streaming kernel, small batches: the 16-wave instantiation takes the short sequences too (one launch per layer)
 };
 
 // The two-pass attention kernel of round 1, kept behind hac_encoder_set_option("attn", "twopass") as the tests' cross-check of
@@ -903,16 +905,22 @@ __global__ __launch_bounds__(WAVES * 64, 4) void attention_stream_kernel(AttnArg
         return v;
     };
     // items of this instantiation's length class: (position in the class's part of the work list, head)
-    const int n_long = sload(a.s.ncls, 0);
+    const int n_long = sload(a.s.ncls, 0) + (WAVES == 16 && a.one_class ? sload(a.s.ncls, 1) : 0);   // (the order list holds the long class first)
     const int list0 = WAVES == 16 ? 0 : n_long;
-    const int n_items = (WAVES == 16 ? n_long : sload(a.s.ncls, 1)) * NH;
+    // Small batches (the reference's 4 queries per call are 48 items on 256 CUs): an item's query rows are dealt to QS workgroups,
+    // WAVES / QS waves of each take 32 rows apiece and the others only help moving K and V.  Fewer waves per SIMD run their steps
+    // faster (the step is bound by the SIMD's VALU issue), more CUs work: 4 x 512 tokens 19 -> ~8 us per layer.  Same arithmetic per row.
+    const int QS = a.cls_only ? 1 : min(a.qsplit, WAVES);
+    const int n_items = (WAVES == 16 ? n_long : sload(a.s.ncls, 1)) * NH * QS;
     auto next_item = [&](int t) { return t + G; };
-    struct Item { int len, len32, head, nch; size_t base; };
+    struct Item { int len, len32, head, nch, q0; size_t base; };
     auto describe = [&](int t) {
-        const int pos = t / NH;
+        const int part = t % QS, th = t / QS;
+        const int pos = th / NH;
         const int b = sload(a.s.order, list0 + pos);
         Item it;
-        it.head = t - pos * NH;
+        it.head = th - pos * NH;
+        it.q0 = part * (WAVES * 32 / QS);
         it.len = sload(a.s.lens, b);
         it.len32 = sload(a.s.len32, b);
         it.base = (size_t)sload(a.s.off, b);
@@ -932,9 +940,9 @@ __global__ __launch_bounds__(WAVES * 64, 4) void attention_stream_kernel(AttnArg
         asm volatile("" : "+v"(l));
         return (unsigned)((l & 31) * 16 + (l >> 5) * 8);
     };
-    auto issue_q = [&](const Item &it) {   // 4 pieces per wave into the Q region (slot = piece)
-        const int p_last = (it.len32 >> 3) - 2 + (w & 1);
-        const bf16 *src = a.q + it.base * H + it.head * DH;
+    auto issue_q = [&](const Item &it) {   // 4 pieces per wave into the Q region (slot = piece), rows from the item's first query row on
+        const int p_last = max((int)(w & 1), ((it.len32 - it.q0) >> 3) - 2 + (w & 1));   // (a part past the sequence's end loads rows it never uses)
+        const bf16 *src = a.q + (it.base + min(it.q0, it.len32 - 32)) * H + it.head * DH;
         const unsigned kl = k_lane();
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -988,7 +996,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void attention_stream_kernel(AttnArg
         const Item nxt = describe(has_next ? tn : t);
         const int len = cur.len, nkb = cur.len32 >> 5;
         const int nfull = len >> 5;            // key blocks without padding keys (nkb - nfull is 0 or 1)
-        const bool active = w * 32 < cur.len32 && !(a.cls_only && w != 0);
+        const bool active = w < WAVES / QS && cur.q0 + w * 32 < cur.len32 && !(a.cls_only && w != 0);
         float m_ref = 0.f, lsum = 0.f;
         f32x16 o[2], negm;
 #pragma unroll
@@ -1100,7 +1108,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void attention_stream_kernel(AttnArg
             // ones: 4 stores of 16 bytes (each a 32-byte run per row) instead of 8 of 8.  Issued by instruction: the wait at the
             // next item's first chunk counts them.
             const float inv = 1.0f / (lsum + __shfl_xor(lsum, 32));
-            bf16 *crow = a.ctx + (cur.base + w * 32 + r) * H + cur.head * DH + 8 * hh;
+            bf16 *crow = a.ctx + (cur.base + cur.q0 + w * 32 + r) * H + cur.head * DH + 8 * hh;
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -1316,6 +1324,7 @@ struct hac_encoder {
     // A/B in one process on the 1000 x 512 forward (tools/ab_encoder.py), two boxes: SPLIT -1 .. -3.4 % on FFN-down (K = 3072),
     // +-1 % (inside the run-to-run spread) on the K = 768 GEMMs; layer stack 93.4 - 94.9 ms with every class split vs 95.3 - 96.7 with none
     int g8_split = 15;
+    int attn_qsplit = -1;  // -1 auto (small batches: query rows of an item dealt to 2 or 4 workgroups), 0 off
     int g8_stagger = -1;   // -1 auto (phased workgroup starts of the K = 768 RESID / QKV classes on long tile runs), 0 off
     void *h_pin = nullptr;
     size_t h_pin_bytes = 0;
@@ -1564,12 +1573,16 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
             g.A = xb; g.W = w.wqkv; g.bias = w.bqkv; g.N = 3 * H; g.K = H; g.q = q; g.k = k; g.v16 = vt;
             HAC_GEMM(EPI_QKV, HAC_ENC_CLASS_QKV);
         }
-        AttnArgs a{q, k, vt, ctx, s, last ? 1 : 0};
+        // (streaming kernels: few sequences -> an item's query rows go to 2 or 4 workgroups while B * NH * qsplit items still fit the CUs)
+        int att_qs = 1;
+        while (e->attn_qsplit != 0 && att_qs < 16 && (long)B * NH * att_qs * 2 <= e->n_cu) att_qs *= 2;
+        const bool att_one = att_qs > 1 && L32 > 256;   // few sequences: one launch (an empty second one is 5 us of a ~100-us layer)
+        AttnArgs a{q, k, vt, ctx, s, last ? 1 : 0, att_qs, att_one ? 1 : 0};
         // sequences of <= 256 rows: 4-wave workgroups; longer ones: 8-wave workgroups (each skips the other's)
         HAC_TRY(prof_begin(e, 1 + HAC_ENC_CLASS_ATTN, st));
         if (e->attn_mode == 0) {           // persistent streaming kernels, one launch per length class
             if (L32 > 256) attention_stream_kernel<16><<<dim3(e->n_cu), dim3(1024), 163840, st>>>(a);
-            attention_stream_kernel<8><<<dim3(2 * e->n_cu), dim3(512), 81920, st>>>(a);
+            if (!att_one) attention_stream_kernel<8><<<dim3(2 * e->n_cu), dim3(512), 81920, st>>>(a);
         } else {                           // two-pass kernels, one workgroup per (sequence, head): kept as a cross-check
             attention_kernel<8, 1><<<dim3(NH, B), dim3(512), (size_t)(L32 < 256 ? L32 : 256) * 256, st>>>(a);
             if (L32 > 256) attention_kernel<16, 1><<<dim3(NH, B), dim3(1024), (size_t)L32 * 256, st>>>(a);
@@ -2030,6 +2043,9 @@ int hac_encoder_set_option(hac_encoder *e, const char *name, const char *value) 
         const long t = strtol(value, &end, 10);
         if (end == value || *end || t < 0 || t > 15) return fail(HAC_ERR_INVALID, "encoder option g8_split = '%s': a bit mask 0..15", value);
         e->g8_split = (int)t;
+    } else if (n == "attn_qsplit") {
+        if (v != "auto" && v != "off") return fail(HAC_ERR_INVALID, "encoder option attn_qsplit = '%s': auto | off", value);
+        e->attn_qsplit = v == "off" ? 0 : -1;
     } else if (n == "g8_stagger") {
         if (v != "auto" && v != "off") return fail(HAC_ERR_INVALID, "encoder option g8_stagger = '%s': auto | off", value);
         e->g8_stagger = v == "off" ? 0 : -1;

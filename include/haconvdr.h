@@ -221,7 +221,9 @@ int hac_encoder_forward_device(hac_encoder *enc, const void *ids_dev, const void
  * on the batch's row count (as it does between the "gemm" families); "off" restores one summation order for every small batch;
  * "max_tokens" = packed rows per sub-batch (integer >= 4096); "g8_split" = bit mask 0..15 (development: which kernel
  * classes -- bit 0 QKV, 1 out-proj, 2 FFN-up, 3 FFN-down -- run the operand-split loop of the large-batch GEMM, default
- * 15; 0 = round 2's loop: same results bit for bit); "g8_stagger" = "auto" (default) | "off" (the workgroups of the large-batch
+ * 15; 0 = round 2's loop: same results bit for bit); "attn_qsplit" = "auto" (default) | "off" (with few sequences the streaming
+ * attention kernel deals the query rows of a (sequence, head) item to 2..16 workgroups and runs both length classes in one launch;
+ * same bits); "g8_stagger" = "auto" (default) | "off" (the workgroups of the large-batch
  * QKV and out-projection GEMMs start in four phases, one per pair of XCDs, so that their epilogues do not reach HBM all at once;
  * timing only, same bits).  Any other name or value is HAC_ERR_INVALID (never a
  * silent default).  HAC_ENC_GEMM gives the default of "gemm" and is read once, in hac_encoder_create.

@@ -553,3 +553,30 @@ def test_small_batch_graph_replay_equals_plain_launches_and_the_oracle():
     assert "graph=replay" in enc.last_plan()
     np.testing.assert_array_equal(a, b)
     np.testing.assert_array_equal(a, out)
+
+
+def test_small_batch_attention_split_same_bits():
+    """Round 4: with few sequences the streaming attention kernel deals an item's query rows to 2..16 workgroups (4 x 512 tokens are
+    48 (sequence, head) items on 256 CUs) and runs both length classes in one launch.  Same arithmetic per row: the same bits as with
+    attn_qsplit = off, for fixed and ragged lengths, long and short sequences mixed, and against the two-pass kernel within rounding."""
+    import torch
+    from haconvdr_amd import synth
+    enc = encoder(2)
+    enc.set_option("graph", "off")
+    for B, L, fixed in ((4, 512, True), (4, 512, False), (1, 512, True), (2, 256, True), (7, 300, False), (3, 40, False), (10, 512, False)):
+        kw = {"fixed_len": L} if fixed else {"min_len": 3}
+        ids, lens = synth.token_batch(4100 + B, B, L, **kw)
+        mask = (np.arange(L)[None, :] < lens[:, None]).astype(np.int64)
+        ids_t, mask_t = torch.from_numpy(ids.astype(np.int64)).cuda(), torch.from_numpy(mask).cuda()
+        enc.set_option("attn_qsplit", "off")
+        ref = enc(ids_t, mask_t).clone()
+        enc.set_option("attn_qsplit", "auto")
+        out = enc(ids_t, mask_t)
+        assert torch.isfinite(out).all()
+        assert torch.equal(out, ref), (B, L, fixed)
+        enc.set_option("attn", "twopass")
+        two = enc(ids_t, mask_t)
+        enc.set_option("attn", "stream")
+        assert one_minus_cos(out.cpu().numpy(), two.cpu().numpy()).max() < 1e-5
+    with pytest.raises(Exception):
+        enc.set_option("attn_qsplit", "4")
