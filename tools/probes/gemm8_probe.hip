@@ -7,16 +7,17 @@
 #include <random>
 #define CK(x) do{hipError_t e_=(x); if(e_!=hipSuccess){printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} }while(0)
 using namespace hac;
+static int GRID = getenv("G8_GRID") ? atoi(getenv("G8_GRID")) : 256;   // workgroups (G8_GRID=16: two per XCD -- is an epilogue slow by itself or because every CU runs one?)
 // SPLIT = true: the shipped form (operand-split DMA roles, 160 KiB); false: round 2's form (128 KiB).  Both in one process,
 // interleaved rounds (cdna_hip_programming.md 5.4 rule 24).
 template <int EPI, bool SPLIT> float run1(Gemm8Args g, int iters){
   const size_t lds = SPLIT ? 163840 : 131072;
   CK(hipFuncSetAttribute((const void*)gemm8_kernel<EPI, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipEvent_t e0,e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  gemm8_kernel<EPI, SPLIT><<<256,512,lds>>>(g);
+  gemm8_kernel<EPI, SPLIT><<<GRID,512,lds>>>(g);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  for(int i=0;i<iters;i++) gemm8_kernel<EPI, SPLIT><<<256,512,lds>>>(g);
+  for(int i=0;i<iters;i++) gemm8_kernel<EPI, SPLIT><<<GRID,512,lds>>>(g);
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms,e0,e1)); CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1)); return ms/iters;
 }
@@ -57,18 +58,18 @@ int main(){
       const size_t nb = c.epi==EPI8_GELU ? (size_t)M*3072*2 : (size_t)M*768*2; bf16* out = c.epi==EPI8_GELU ? h : (c.epi==EPI8_RESID ? yb : k);
       std::vector<unsigned short> a(nb/2), b(nb/2);
       CK(hipMemset(out, 0xff, nb));
-      if(c.epi==EPI8_QKV) gemm8_kernel<EPI8_QKV,false><<<256,512,131072>>>(g); if(c.epi==EPI8_RESID) gemm8_kernel<EPI8_RESID,false><<<256,512,131072>>>(g); if(c.epi==EPI8_GELU) gemm8_kernel<EPI8_GELU,false><<<256,512,131072>>>(g);
+      if(c.epi==EPI8_QKV) gemm8_kernel<EPI8_QKV,false><<<GRID,512,131072>>>(g); if(c.epi==EPI8_RESID) gemm8_kernel<EPI8_RESID,false><<<GRID,512,131072>>>(g); if(c.epi==EPI8_GELU) gemm8_kernel<EPI8_GELU,false><<<GRID,512,131072>>>(g);
       CK(hipDeviceSynchronize()); CK(hipMemcpy(a.data(), out, nb, hipMemcpyDeviceToHost));
       CK(hipMemset(out, 0xff, nb));
-      if(c.epi==EPI8_QKV) gemm8_kernel<EPI8_QKV,true><<<256,512,163840>>>(g); if(c.epi==EPI8_RESID) gemm8_kernel<EPI8_RESID,true><<<256,512,163840>>>(g); if(c.epi==EPI8_GELU) gemm8_kernel<EPI8_GELU,true><<<256,512,163840>>>(g);
+      if(c.epi==EPI8_QKV) gemm8_kernel<EPI8_QKV,true><<<GRID,512,163840>>>(g); if(c.epi==EPI8_RESID) gemm8_kernel<EPI8_RESID,true><<<GRID,512,163840>>>(g); if(c.epi==EPI8_GELU) gemm8_kernel<EPI8_GELU,true><<<GRID,512,163840>>>(g);
       CK(hipDeviceSynchronize()); CK(hipMemcpy(b.data(), out, nb, hipMemcpyDeviceToHost));
       size_t diff = 0; for (size_t i = 0; i < a.size(); ++i) diff += a[i] != b[i];
       printf("   outputs of the two forms differ in %zu of %zu elements\n", diff, a.size()); }
 #ifdef G8_STAMP2
     for (int form = 0; form < 2; ++form) {
       CK(hipMemset(part, 0, 2048));
-      if (form) { if(c.epi==EPI8_QKV) gemm8_kernel<EPI8_QKV,true><<<256,512,163840>>>(g); if(c.epi==EPI8_RESID) gemm8_kernel<EPI8_RESID,true><<<256,512,163840>>>(g); if(c.epi==EPI8_GELU) gemm8_kernel<EPI8_GELU,true><<<256,512,163840>>>(g); }
-      else { if(c.epi==EPI8_QKV) gemm8_kernel<EPI8_QKV,false><<<256,512,131072>>>(g); if(c.epi==EPI8_RESID) gemm8_kernel<EPI8_RESID,false><<<256,512,131072>>>(g); if(c.epi==EPI8_GELU) gemm8_kernel<EPI8_GELU,false><<<256,512,131072>>>(g); }
+      if (form) { if(c.epi==EPI8_QKV) gemm8_kernel<EPI8_QKV,true><<<GRID,512,163840>>>(g); if(c.epi==EPI8_RESID) gemm8_kernel<EPI8_RESID,true><<<GRID,512,163840>>>(g); if(c.epi==EPI8_GELU) gemm8_kernel<EPI8_GELU,true><<<GRID,512,163840>>>(g); }
+      else { if(c.epi==EPI8_QKV) gemm8_kernel<EPI8_QKV,false><<<GRID,512,131072>>>(g); if(c.epi==EPI8_RESID) gemm8_kernel<EPI8_RESID,false><<<GRID,512,131072>>>(g); if(c.epi==EPI8_GELU) gemm8_kernel<EPI8_GELU,false><<<GRID,512,131072>>>(g); }
       CK(hipDeviceSynchronize());
       unsigned long long hs[96]; CK(hipMemcpy(hs, part, sizeof hs, hipMemcpyDeviceToHost));
       for (int gq = 0; gq < 2; ++gq) { unsigned long long* h = hs + 64 + gq*16;
