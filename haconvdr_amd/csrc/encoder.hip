@@ -1688,6 +1688,7 @@ void drop_graphs(hac_encoder *e) {
     }
     e->graphs.clear();
 }
+constexpr size_t GRAPH_MAX_SHAPES = 64;   // captured (B, L, options) shapes kept per encoder
 bool graph_eligible(const hac_encoder *e, int B, int L, hipStream_t st) {
     if (e->graph_mode == 0 || e->prof_mask != 0) return false;
     const int L32 = (L + SEQ_ALIGN - 1) / SEQ_ALIGN * SEQ_ALIGN;
@@ -1704,6 +1705,9 @@ int forward_graph(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, f
     HAC_TRY(e->ws_gout.reserve(n_out));
     const uint64_t key = ((uint64_t)B << 40) | ((uint64_t)L << 24) | ((uint64_t)sizeof(IT) << 16) | ((uint64_t)(e->attn_mode & 1) << 8) |
                          ((uint64_t)((e->gemm_mode + 1) & 3) << 4) | (uint64_t)(e->g8_split & 15) | ((uint64_t)(e->ksplit_mode & 1) << 12);
+    // (a caller that pads every batch to its own longest sequence can show hundreds of shapes: the cache is bounded, and starting
+    // over costs each live shape one plain forward and one capture)
+    if (e->graphs.size() >= GRAPH_MAX_SHAPES && e->graphs.find(key) == e->graphs.end()) drop_graphs(e);
     hac_encoder::GraphEntry &ge = e->graphs[key];
     const IT *gids = (const IT *)e->ws_gids.p, *gmask = (const IT *)e->ws_gmask.p;
     float *gout = (float *)e->ws_gout.p;

@@ -214,7 +214,8 @@ int hac_encoder_forward_device(hac_encoder *enc, const void *ids_dev, const void
  * src/test_HAConvDR_topiocqa.py:173,406: ~110 launches for ~0.4 TFLOP) are captured ONCE per (B, L, elem_bytes, options) into a HIP
  * graph over private input / output buffers and replayed -- per call one graph launch and three small device copies; the first call
  * of a shape runs plain launches (it sizes the workspaces), the second captures, later ones replay; results are the same bits as
- * with "off".  Not used while profiling is on or while the caller's stream is itself capturing;
+ * with "off" (at most 64 shapes are kept per encoder; beyond that the cache starts over).  Not used while profiling is on or while
+ * the caller's stream is itself capturing;
  * "ksplit" = "auto" (default) | "off": with few rows (the classic 128^2 kernels, fewer than ~1.5 output tiles per CU) the two
  * residual GEMMs of a layer split their K loop over 2..16 work items per tile, the partial sums being added in a fixed order by
  * the LayerNorm pass behind them: deterministic, but the summation order -- hence the last bits of an embedding -- then depends

@@ -580,3 +580,23 @@ def test_small_batch_attention_split_same_bits():
         assert one_minus_cos(out.cpu().numpy(), two.cpu().numpy()).max() < 1e-5
     with pytest.raises(Exception):
         enc.set_option("attn_qsplit", "4")
+
+
+def test_graph_cache_is_bounded_and_survives_being_dropped():
+    """A caller that pads each batch to its own longest sequence shows the encoder many (B, L) shapes: the graph cache holds 64 of
+    them and starts over beyond that.  Results never depend on whether a call ran plain, captured, replayed or re-captured."""
+    import torch
+    from haconvdr_amd import synth
+    from haconvdr_amd.encoder import ANCEEncoder
+    sd = state_dict(2)
+    enc, ref_enc = ANCEEncoder.from_state_dict(sd), ANCEEncoder.from_state_dict(sd)    # (two handles: the helper's is shared)
+    ref_enc.set_option("graph", "off")
+    shapes = [(1 + (i % 3), 8 + 7 * i) for i in range(70)]             # 70 distinct (B, L), L up to 491
+    for rnd in range(2):
+        for B, L in shapes + shapes[:3]:
+            ids, lens = synth.token_batch(6000 + 13 * L + B, B, L, min_len=4)
+            mask = (np.arange(L)[None, :] < lens[:, None]).astype(np.int64)
+            ids_t, mask_t = torch.from_numpy(ids.astype(np.int64)).cuda(), torch.from_numpy(mask).cuda()
+            out = enc(ids_t, mask_t)
+            assert torch.equal(out, ref_enc(ids_t, mask_t)), (rnd, B, L, enc.last_plan())
+    assert "graph=" in enc.last_plan() and "graph=off" not in enc.last_plan()
