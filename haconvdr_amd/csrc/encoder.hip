@@ -379,6 +379,9 @@ __device__ __forceinline__ float gelu_erf(float x) { return gelu_erf2((f2v){x, x
 // PERSISTENT: one workgroup per CU slot walks a list of output tiles; the first k-tile of the NEXT
 // output tile is staged during the last k-step of the current one, so neither the first-load latency
 // nor the epilogue's stores are exposed (K = 768 means only 12 k-steps per tile).
+#ifndef HAC_RESID_SCALAR_LN
+#define HAC_RESID_SCALAR_LN 1
+#endif
 template <int EPI, int TMT>
 __global__ __launch_bounds__(TMT * 128, 2) void gemm_bf16_nt_kernel(GemmArgs g) {
     // LDS: two stages of {A tile BMx64, W tile BNx64} bf16 + one 4 KiB transpose patch per wave.
@@ -592,7 +595,24 @@ __global__ __launch_bounds__(TMT * 128, 2) void gemm_bf16_nt_kernel(GemmArgs g) 
 #pragma unroll
                         for (int it = 0; it < 4; ++it) {
                             const float2 st = g.rstats[mr + it * 4 + (lane >> 4)];
+#if HAC_RESID_SCALAR_LN
+                            // Component by component, each value pinned to a VGPR of its own, so that hipcc cannot form packed-fp32
+                            // instructions here.  With the vector expression it emitted v_sub_f32 x 4, v_pk_mul_f32 ... op_sel:[0,1] (both
+                            // halves times rstd, the high word of the statistics pair) and v_pk_fma_f32 right behind the loads' waits, and on
+                            // MI355X the LOW half of such a packed result was now and then wrong for one 16-lane pass: one element in a few
+                            // thousand forwards of 6-16 k rows (found by the encoder soak in round 4; a forward repeated on the same input
+                            // differed in one sequence in ~5 % of the runs).  Not reproduced with scalar instructions.
+                            float c0 = rs[it].x, c1 = rs[it].y, c2 = rs[it].z, c3 = rs[it].w, mean = st.x, rstd = st.y;
+                            asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(mean), "+v"(rstd));
+                            c0 = fmaf((c0 - mean) * rstd, gam.x, bet.x);
+                            c1 = fmaf((c1 - mean) * rstd, gam.y, bet.y);
+                            c2 = fmaf((c2 - mean) * rstd, gam.z, bet.z);
+                            c3 = fmaf((c3 - mean) * rstd, gam.w, bet.w);
+                            asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+                            rs[it] = (f4v){c0, c1, c2, c3};
+#else
                             rs[it] = (rs[it] - st.x) * st.y * gam + bet;
+#endif
                         }
                     }
                 }
@@ -1631,6 +1651,7 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
             HAC_TRY(prof_begin(e, 1 + HAC_ENC_CLASS_LN, st));
             ln_stats_rows_kernel<<<dim3((unsigned)(Mp / 4)), dim3(256), 0, st>>>(y, total, w.ln1g, w.ln1b, c.ln_eps, statsA, xb, kpart, ks_out - 1, part_stride);
             HAC_TRY(prof_end(e, 1 + HAC_ENC_CLASS_LN, st));
+
             // FFN
             g.A = xb; g.W = w.w1; g.bias = w.b1; g.N = FF; g.K = H; g.h = h;
             HAC_GEMM(EPI_GELU, HAC_ENC_CLASS_FFN_UP);
@@ -1642,6 +1663,7 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
             HAC_TRY(prof_begin(e, 1 + HAC_ENC_CLASS_LN, st));
             ln_stats_rows_kernel<<<dim3((unsigned)(Mp / 4)), dim3(256), 0, st>>>(x, total, w.ln2g, w.ln2b, c.ln_eps, statsF, xb, kpart, ks_down - 1, part_stride);
             HAC_TRY(prof_end(e, 1 + HAC_ENC_CLASS_LN, st));
+
         } else {
             // only the <s> row of every sequence continues (B rows instead of T): same kernels, compact matrices
             gather_cls_kernel<<<dim3((unsigned)Mc), dim3(256), 0, st>>>(ctx, x, g8 ? xb : nullptr, defer_in ? statsF : nullptr, ln2g_prev, ln2b_prev, s, B, ctx_c, x_c);

@@ -600,3 +600,28 @@ def test_graph_cache_is_bounded_and_survives_being_dropped():
             out = enc(ids_t, mask_t)
             assert torch.equal(out, ref_enc(ids_t, mask_t)), (rnd, B, L, enc.last_plan())
     assert "graph=" in enc.last_plan() and "graph=off" not in enc.last_plan()
+
+
+@pytest.mark.parametrize("B,L,gemm", [(130, 64, "auto"), (100, 64, "auto"), (33, 256, "auto"), (130, 128, "classic"), (66, 512, "auto")])
+def test_a_forward_repeated_on_the_same_input_gives_the_same_bits(B, L, gemm):
+    """Round 4: the encoder soak caught ONE mismatching sequence in ~6000 batches; repeated on the same input, a forward of 6-16 k
+    packed rows through the 128-row GEMM family differed in one sequence in ~5 % of the runs: in the residual GEMM's deferred-LayerNorm
+    arithmetic the LOW half of a packed-fp32 result (v_pk_mul_f32 ... op_sel / v_pk_fma_f32 right behind the loads' waits) was wrong for
+    one 16-lane pass now and then.  That arithmetic is scalar now; every family must be bit-reproducible run after run."""
+    from haconvdr_amd import synth
+    enc = encoder(2)
+    enc.set_option("graph", "off")
+    enc.set_option("gemm", gemm)
+    try:
+        rng = np.random.default_rng(B * 1000 + L)
+        bad = 0
+        for rep in range(12):
+            ids, _ = synth.token_batch(int(rng.integers(1 << 30)), B, L, fixed_len=L)
+            mask = np.ones_like(ids)
+            first = enc(ids, mask)
+            for _ in range(12):
+                bad += not np.array_equal(enc(ids, mask), first)
+        assert bad == 0, (bad, enc.last_plan())
+    finally:
+        enc.set_option("gemm", "auto")
+        enc.set_option("graph", "auto")

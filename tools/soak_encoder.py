@@ -1,7 +1,7 @@
 """Development: soak of the encoder -- one handle encodes a stream of random batches (sizes, lengths, both GEMM families); every
 batch is encoded again by a FRESH handle with the same weights: the two must agree bit for bit (nothing a call leaves behind in
 the workspaces may reach the next one).
-  python tools/soak_encoder.py [seed] [seconds] [layers]"""
+  python tools/soak_encoder.py [seed] [seconds] [layers] [option=value ...]   (options go to BOTH handles)"""
 import os
 import sys
 import time
@@ -20,7 +20,10 @@ def main():
     layers = int(sys.argv[3]) if len(sys.argv) > 3 else 2
     rng = np.random.default_rng(seed)
     sd = synth.ance_state_dict(0xA11CE, layers)
+    opts = [a.split("=", 1) for a in sys.argv[4:]]
     enc = ANCEEncoder.from_state_dict(sd)
+    for name, value in opts:
+        enc.set_option(name, value)
     t0 = time.time()
     n = 0
     while time.time() - t0 < budget:
@@ -32,6 +35,8 @@ def main():
         out = enc(ids, mask)
         plan = enc.last_plan()
         fresh = ANCEEncoder.from_state_dict(sd)
+        for name, value in opts:
+            fresh.set_option(name, value)
         ref = fresh(ids, mask)
         del fresh
         if not np.array_equal(out, ref):
