@@ -15,8 +15,9 @@ rng = np.random.default_rng(7)
 t0 = time.time(); n = 0; bad = 0; nrows = 0
 while time.time() - t0 < budget:
     b = int(rng.choice(Bs)); lmax = int(rng.choice(Ls))
-    ids, lens = synth.token_batch(int(rng.integers(1 << 30)), b, lmax, fixed_len=lmax)
-    mask = np.ones_like(ids)
+    fixed = bool(rng.integers(0, 2))
+    ids, lens = synth.token_batch(int(rng.integers(1 << 30)), b, lmax, fixed_len=lmax if fixed else None)
+    mask = (np.arange(lmax)[None, :] < lens[:, None]).astype(ids.dtype)
     a = enc(ids, mask); c = enc(ids, mask)
     n += 1
     if not np.array_equal(a, c):
