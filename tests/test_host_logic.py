@@ -257,3 +257,14 @@ def test_prefilter_scan_kernels_keep_everything_in_registers_and_fit_the_lds():
     assert seen == 4          # <1,false>, <1,true>, <3,false>, <3,true>
     src = open(os.path.join(ROOT, "haconvdr_amd", "csrc", "scan_split.inc")).read()
     assert "static_assert(LDS <= 163840" in src
+
+
+def test_every_tool_is_valid_python():
+    """tools/*.py are run by hand or through gpurun, some only once a round: a syntax error there is found when it is needed."""
+    import ast
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "tools", "*.py")))
+    assert len(files) >= 8
+    for f in files:
+        ast.parse(open(f).read(), filename=f)
