@@ -703,6 +703,7 @@ __global__ __launch_bounds__(W * 64) void scanq_kernel(ScanArgs a) {
             if (__builtin_expect(*(volatile u32 *)(ovf + 2) != 0u, 0)) {   // workgroup-uniform
                 static_assert(NQ <= NTHR, "one thread per query of the tile");
                 scan_overrun(a, q0, NQr, tid);   // poisoned tile, on with the next round
+                __syncthreads();                 // every wave has read ovf[2] before tid 0 clears it below (as in scanh_kernel)
                 break;
             }
         }

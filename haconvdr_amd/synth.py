@@ -108,18 +108,25 @@ def _name_seed(seed, name):
     return int(h)
 
 
-def ance_state_dict(seed=0xA11CE, n_layers=12, hidden=768, ffn=3072, vocab=50265, max_pos=514, rich=True):
+def ance_state_dict(seed=0xA11CE, n_layers=12, hidden=768, ffn=3072, vocab=50265, max_pos=514, rich=True, layer_matrix_std=0.02):
     """Synthetic weights with the reference checkpoint's key names (``roberta.*``,
     ``embeddingHead.*``, ``norm.*``): dict name -> float32 ndarray.
 
     Matrices ~ N(0, 0.02²) (the reference's init, src/models.py:37).  rich=True also randomises
     biases (sd 0.02) and LayerNorm affine (gamma 1 ± 0.1, beta sd 0.05) so that every parameter
     influences the output — used by the parity tests; rich=False is the survey's bench recipe
-    (biases 0, LN identity)."""
+    (biases 0, LN identity).
+
+    layer_matrix_std: standard deviation of the six matrices of every encoder layer (embeddings and
+    head keep 0.02).  At 0.02 a random RoBERTa maps all inputs onto nearly one direction (pairwise
+    1−cos between different sequences' embeddings 1e-4 … 2e-3): parity asserts on such outputs cannot
+    tell one sequence from another.  0.08 ("content-sensitive": attention logits of σ ≈ 5, different
+    sequences ≥ 0.05 apart in 1−cos) is what the discriminative goldens use."""
     sd = {}
 
     def mat(name, shape):
-        sd[name] = normal_fast(_name_seed(seed, name), shape, 0.02)
+        std = layer_matrix_std if name.startswith("roberta.encoder.layer.") else 0.02
+        sd[name] = normal_fast(_name_seed(seed, name), shape, std)
 
     def vec(name, n, kind):
         if not rich:

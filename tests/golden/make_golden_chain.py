@@ -31,16 +31,19 @@ from tests.golden.stub_tokenizer import StubTokenizer  # noqa: E402
 
 CHAIN = dict(weights_seed=0xC4A1, n_layers=2, corpus_seed=0xC0895, corpus_rows=900, blocks=3, passage_block_num=5, top_k=20,
              test_type="convqa", max_query_length=32, max_doc_length=256, max_response_length=64, max_concat_length=128,
-             per_gpu_test_batch_size=4, n_gpu=1, seed=42, use_PRL=False)
+             per_gpu_test_batch_size=4, n_gpu=1, seed=42, use_PRL=False,
+             # round 5: content-sensitive weights (synth.ance_state_dict's docstring): the reference's embeddings of
+             # different queries are >= 0.05 apart in 1-cos, so the encode leg's bound can tell them apart
+             layer_matrix_std=0.08)
 
 
-def write_checkpoint(path, seed, n_layers):
+def write_checkpoint(path, seed, n_layers, layer_matrix_std=0.02):
     """config.json + model.safetensors of a synthetic ANCE checkpoint (the key names of the reference's state dict)."""
     import json
     import torch
     from safetensors.torch import save_file
     os.makedirs(path, exist_ok=True)
-    sd = synth.ance_state_dict(seed, n_layers)
+    sd = synth.ance_state_dict(seed, n_layers, layer_matrix_std=layer_matrix_std)
     save_file({k: torch.from_numpy(v).contiguous() for k, v in sd.items()}, os.path.join(path, "model.safetensors"), metadata={"format": "pt"})
     cfg = {"architectures": ["RobertaForSequenceClassification"], "model_type": "roberta", "vocab_size": 50265, "hidden_size": 768,
            "num_hidden_layers": n_layers, "num_attention_heads": 12, "intermediate_size": 3072, "hidden_act": "gelu",
@@ -96,7 +99,7 @@ def main():
     ref.print_trec_res = lambda *a, **k: {"stub": True}
     ref.build_faiss_index = lambda args: NumpyFmafIndex(768)
     with tempfile.TemporaryDirectory() as tmp:
-        write_checkpoint(os.path.join(tmp, "ckpt"), CHAIN["weights_seed"], CHAIN["n_layers"])
+        write_checkpoint(os.path.join(tmp, "ckpt"), CHAIN["weights_seed"], CHAIN["n_layers"], CHAIN["layer_matrix_std"])
         write_corpus(os.path.join(tmp, "emb"), CHAIN["corpus_seed"], CHAIN["corpus_rows"], CHAIN["blocks"])
         args = chain_args(tmp)
         args.device = torch.device("cpu")

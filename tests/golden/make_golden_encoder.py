@@ -34,27 +34,42 @@ def encoder_case_inputs(seed, lens, L):
     return ids, mask
 
 
+def big_case_lens(seed, n, lo, hi):
+    """n lengths in [lo, hi] from the build's own generator (the big fixture stores seeds, not 164k token ids)."""
+    return (lo + (synth.uniform_u32(seed, n) % np.uint32(hi - lo + 1))).astype(np.int64).tolist()
+
+
+SENS_STD = 0.08   # synth.ance_state_dict(layer_matrix_std=...): content-sensitive weights, see its docstring
+
 CASES = [
-    # name, n_layers, L, lens, special
-    ("l2_mixed", 2, 512, [5, 33, 64, 100, 257, 384, 511, 512], "tok1"),
-    ("l2_full384", 2, 384, [384, 384, 384, 384], None),
-    ("l12_mixed", 12, 512, [8, 31, 64, 129, 256, 384, 512, 40], "tok1"),
-    ("l12_qrecc256", 12, 256, [256, 17, 200, 64], None),
+    # name, n_layers, L, lens, special, layer_matrix_std
+    ("l2_mixed", 2, 512, [5, 33, 64, 100, 257, 384, 511, 512], "tok1", 0.02),
+    ("l2_full384", 2, 384, [384, 384, 384, 384], None, 0.02),
+    ("l12_mixed", 12, 512, [8, 31, 64, 129, 256, 384, 512, 40], "tok1", 0.02),
+    ("l12_qrecc256", 12, 256, [256, 17, 200, 64], None, 0.02),
+    # round 5: content-sensitive weights -- different sequences' embeddings are >= 0.05 apart in 1-cos, so a parity bound
+    # of a tenth of that spread rejects a wrong row, a dropped layer or a tile-shifted varlen offset
+    ("l2_sens_full384", 2, 384, [384] * 6, None, SENS_STD),
+    ("l12_sens_mixed", 12, 512, [8, 31, 64, 129, 256, 384, 512, 40, 500, 333], "tok1", SENS_STD),
+    # 320 x 512 padded: auto-routed through the large-batch GEMM family; ids are regenerated from the seed by the test
+    ("l12_sens_big320", 12, 512, big_case_lens(0x5E75, 320, 48, 512), "seeded", SENS_STD),
 ]
 
 
-def main():
+def main(only=None):
     sys.path[:0] = [REF, os.path.join(REF, "src")]
     import torch
     import models  # the reference's src/models.py
     from transformers import RobertaConfig
-    for name, n_layers, L, lens, special in CASES:
+    for name, n_layers, L, lens, special, mstd in CASES:
+        if only and name not in only:
+            continue
         seed = int.from_bytes(name.encode()[:4], "little")
         cfg = RobertaConfig(vocab_size=50265, hidden_size=768, num_hidden_layers=n_layers, num_attention_heads=12,
                             intermediate_size=3072, max_position_embeddings=514, type_vocab_size=1, layer_norm_eps=1e-5,
                             pad_token_id=1, bos_token_id=0, eos_token_id=2)
         model = models.ANCE(cfg).eval()
-        sd = synth.ance_state_dict(0xA11CE, n_layers)
+        sd = synth.ance_state_dict(0xA11CE, n_layers, layer_matrix_std=mstd)
         missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
         assert not unexpected and all(m.startswith("classifier.") or "position_ids" in m for m in missing), (missing, unexpected)
         ids, mask = encoder_case_inputs(seed, lens, L)
@@ -62,7 +77,15 @@ def main():
             ids[1, 3] = 1        # RoBERTa's pad id INSIDE a sequence: exercises the cumsum position rule
             ids[6, 100] = 1
         with torch.no_grad():
-            out = model(torch.from_numpy(ids), torch.from_numpy(mask)).numpy()
+            out = np.concatenate([model(torch.from_numpy(ids[b:b + 32]), torch.from_numpy(mask[b:b + 32])).numpy()
+                                  for b in range(0, len(lens), 32)])
+        if special == "seeded":
+            # the reference's outputs + everything needed to regenerate the inputs (encoder_case_inputs(seed, lens, L))
+            np.savez_compressed(os.path.join(HERE, f"encoder_{name}.npz"), seed=seed, n_layers=n_layers, L=L, lens=np.array(lens),
+                                ids_sum=ids.sum(dtype=np.int64), ids_xor=np.bitwise_xor.reduce(ids.ravel()), ref_out=out,
+                                layer_matrix_std=mstd)
+            print(name, out.shape, "ids regenerated from the seed by the tests")
+            continue
         # the reference's result must not depend on what sits in masked positions (SURVEY §3.3 [probed])
         ids2 = ids.copy()
         ids2[mask == 0] = 1
@@ -70,9 +93,23 @@ def main():
             out2 = model(torch.from_numpy(ids2), torch.from_numpy(mask)).numpy()
         np.savez_compressed(os.path.join(HERE, f"encoder_{name}.npz"), seed=seed, n_layers=n_layers, L=L, lens=np.array(lens),
                             ids=ids.astype(np.int32), mask=mask.astype(np.int8), ref_out=out,
-                            pad_invariance_maxdiff=np.abs(out - out2).max())
+                            pad_invariance_maxdiff=np.abs(out - out2).max(), layer_matrix_std=mstd)
         print(name, out.shape, out.dtype, "norm", np.linalg.norm(out[0]), "pad-invariance", np.abs(out - out2).max())
 
 
+def load_case(path):
+    """(ids int32 [B, L], mask int32 [B, L], reference output, n_layers, layer_matrix_std) of a fixture; the big
+    fixture's token ids are regenerated from its seed and checked against the stored checksums."""
+    g = np.load(path)
+    mstd = float(g["layer_matrix_std"]) if "layer_matrix_std" in g.files else 0.02
+    if "ids" in g.files:
+        ids, mask = g["ids"].astype(np.int32), g["mask"].astype(np.int32)
+    else:
+        ids, mask = encoder_case_inputs(int(g["seed"]), [int(v) for v in g["lens"]], int(g["L"]))
+        assert int(ids.sum(dtype=np.int64)) == int(g["ids_sum"]) and int(np.bitwise_xor.reduce(ids.ravel())) == int(g["ids_xor"])
+        ids, mask = ids.astype(np.int32), mask.astype(np.int32)
+    return ids, mask, g["ref_out"], int(g["n_layers"]), mstd
+
+
 if __name__ == "__main__":
-    main()
+    main(set(sys.argv[1:]))

@@ -1,0 +1,85 @@
+"""Discriminative parity metrics for encoder outputs (test infrastructure).
+
+Why: with N(0, 0.02²) weights a random RoBERTa maps every input onto nearly one direction -- the reference's outputs for
+DIFFERENT sequences of tests/golden/encoder_l2_full384.npz are 1.7e-4 apart in 1−cos -- so a fixed `1−cos < 1e-3` assert
+(BASELINE.json's contract) cannot tell a right row from a wrong one.  Every encoder parity assert goes through
+``assert_embeddings_match``, which scales its bounds to the fixture:
+
+* raw cosine:      1−cos(out_i, ref_i) ≤ min(contract 1e-3, FRACTION · min_{i≠j} 1−cos(ref_i, ref_j))
+* centred cosine:  the same after subtracting the REFERENCE's batch-mean embedding from out and ref (the common direction
+                   all rows share is removed: what is left is what distinguishes the rows)
+* relative L2:     ‖out_i − ref_i‖ / ‖ref_i − mean‖ ≤ REL_L2  (a wrong row scores ≈ √2)
+
+``spread`` reports the fixture's own inter-sequence distances; ``embeddings_match`` is the boolean twin used by the negative
+controls (rows permuted by one must NOT match).
+"""
+import numpy as np
+
+CONTRACT = 1e-3      # BASELINE.json north_star: embedding cosines within 1e-3 of the reference CPU path
+FRACTION = 0.1       # of the fixture's minimum inter-sequence distance
+REL_L2 = 0.25        # of the row's distance from the batch mean
+
+
+def one_minus_cos(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return 1.0 - (a * b).sum(-1) / (np.linalg.norm(a, axis=-1) * np.linalg.norm(b, axis=-1))
+
+
+def _pairwise_min(x):
+    x = np.asarray(x, np.float64)
+    n = x / np.linalg.norm(x, axis=1, keepdims=True)
+    c = 1.0 - n @ n.T
+    c[np.diag_indices(len(x))] = np.inf
+    return c.min(axis=1)
+
+
+def spread(ref):
+    """dict: min / median pairwise 1−cos between different rows of ref, raw and centred."""
+    ref = np.asarray(ref, np.float64)
+    raw = _pairwise_min(ref)
+    cen = _pairwise_min(ref - ref.mean(0, keepdims=True))
+    return {"raw_min": float(raw.min()), "raw_median": float(np.median(raw)), "centred_min": float(cen.min())}
+
+
+def measure(out, ref):
+    """dict of the three error figures (max over rows) and the fixture's bounds."""
+    out, ref = np.asarray(out, np.float64), np.asarray(ref, np.float64)
+    assert out.shape == ref.shape and ref.ndim == 2 and len(ref) >= 3, "need >= 3 rows for an inter-sequence spread"
+    mu = ref.mean(0, keepdims=True)
+    sp = spread(ref)
+    return {
+        "raw": float(one_minus_cos(out, ref).max()),
+        "raw_bound": min(CONTRACT, FRACTION * sp["raw_min"]),
+        "centred": float(one_minus_cos(out - mu, ref - mu).max()),
+        "centred_bound": FRACTION * sp["centred_min"],
+        "rel_l2": float((np.linalg.norm(out - ref, axis=1) / np.linalg.norm(ref - mu, axis=1)).max()),
+        "rel_l2_bound": REL_L2,
+        "spread": sp,
+    }
+
+
+def embeddings_match(out, ref, raw_bound=None):
+    """True when all three figures are inside their bounds.  raw_bound overrides the per-fixture raw-cosine bound (used where
+    a fixture's rows are closer together than ten times the bf16 path's own rounding noise: the centred figures still
+    discriminate there)."""
+    if not np.isfinite(np.asarray(out)).all():
+        return False
+    m = measure(out, ref)
+    rb = m["raw_bound"] if raw_bound is None else raw_bound
+    return m["raw"] <= rb and m["centred"] <= m["centred_bound"] and m["rel_l2"] <= m["rel_l2_bound"]
+
+
+def assert_embeddings_match(out, ref, raw_bound=None, what=""):
+    m = measure(out, ref)
+    rb = m["raw_bound"] if raw_bound is None else raw_bound
+    assert np.isfinite(np.asarray(out)).all(), what
+    assert m["raw"] <= rb, (what, "1-cos", m["raw"], "bound", rb, m["spread"])
+    assert m["centred"] <= m["centred_bound"], (what, "centred 1-cos", m["centred"], "bound", m["centred_bound"])
+    assert m["rel_l2"] <= m["rel_l2_bound"], (what, "relative L2", m["rel_l2"], "bound", m["rel_l2_bound"])
+    return m
+
+
+def assert_negative_control(out, ref, raw_bound=None):
+    """The bounds must reject the same embeddings assigned to the wrong sequences (rows rotated by one)."""
+    assert not embeddings_match(np.roll(np.asarray(out), 1, axis=0), ref, raw_bound), \
+        "the parity bounds accept another sequence's embedding: the fixture / bound is not discriminative"

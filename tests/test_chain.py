@@ -25,7 +25,7 @@ TOPK = int(G["top_k"])
 def chain_dir(tmp_path_factory):
     """Checkpoint directory + passage blocks + offset2pid regenerated from the fixture's seeds."""
     tmp = str(tmp_path_factory.mktemp("chain"))
-    sd = mk.write_checkpoint(os.path.join(tmp, "ckpt"), int(G["weights_seed"]), int(G["n_layers"]))
+    sd = mk.write_checkpoint(os.path.join(tmp, "ckpt"), int(G["weights_seed"]), int(G["n_layers"]), float(G["layer_matrix_std"]))
     x, offset2pid = mk.write_corpus(os.path.join(tmp, "emb"), int(G["corpus_seed"]), int(G["corpus_rows"]), int(G["blocks"]))
     return tmp, sd, x, offset2pid
 

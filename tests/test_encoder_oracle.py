@@ -10,11 +10,12 @@ GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "encod
 _SD = {}
 
 
-def state_dict(n_layers):
+def state_dict(n_layers, layer_matrix_std=0.02):
     from haconvdr_amd import synth
-    if n_layers not in _SD:
-        _SD[n_layers] = synth.ance_state_dict(0xA11CE, n_layers)
-    return _SD[n_layers]
+    key = (n_layers, layer_matrix_std)
+    if key not in _SD:
+        _SD[key] = synth.ance_state_dict(0xA11CE, n_layers, layer_matrix_std=layer_matrix_std)
+    return _SD[key]
 
 
 def cosine(a, b):
@@ -22,20 +23,31 @@ def cosine(a, b):
 
 
 def test_encoder_goldens_present():
-    assert len(GOLD) >= 4
+    assert len(GOLD) >= 7
 
 
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[8:-4] for p in GOLD])
 def test_oracle_matches_reference_ance(path):
     from oracle import ance_oracle
-    g = np.load(path)
-    out = ance_oracle.ance_forward(state_dict(int(g["n_layers"])), g["ids"].astype(np.int64), g["mask"].astype(np.int64))
-    ref = g["ref_out"]
-    assert out.shape == ref.shape == (len(g["lens"]), 768) and out.dtype == np.float32
-    # fp32 vs fp32 (sdpa vs explicit softmax): tolerance 2e-4 absolute on outputs of norm ~27.7, cosine 1e-6
-    np.testing.assert_allclose(out, ref, atol=2e-4, rtol=0)
+    from tests import parity
+    from tests.golden.make_golden_encoder import load_case
+    ids, mask, ref, n_layers, mstd = load_case(path)
+    assert ref.shape == (len(ids), 768)
+    if len(ids) > 32:      # the 320-sequence fixture: twelve rows spread over it (the whole batch is minutes of CPU)
+        pick = np.r_[0:len(ids):29][:12]
+        ids, mask, ref = ids[pick], mask[pick], ref[pick]
+    out = ance_oracle.ance_forward(state_dict(n_layers, mstd), ids.astype(np.int64), mask.astype(np.int64))
+    assert out.shape == ref.shape and out.dtype == np.float32
+    # fp32 vs fp32 (sdpa vs explicit softmax): 2e-4 absolute on outputs of norm ~27.7 with the reference's init; the
+    # content-sensitive weights (layer matrices x 4) amplify reassociation noise by about as much
+    np.testing.assert_allclose(out, ref, atol=2e-4 if mstd == 0.02 else 1e-3, rtol=0)
     assert np.all(1.0 - cosine(out, ref) < 1e-6)
-    assert float(g["pad_invariance_maxdiff"]) == 0.0
+    m = parity.assert_embeddings_match(out, ref, what=os.path.basename(path))
+    parity.assert_negative_control(out, ref)
+    assert m["raw"] < 0.01 * m["spread"]["raw_min"]          # the oracle is a hundred times closer to the reference than two of its rows are
+    g = np.load(path)
+    if "pad_invariance_maxdiff" in g.files:
+        assert float(g["pad_invariance_maxdiff"]) == 0.0
 
 
 def test_oracle_varlen_equals_padded():

@@ -270,33 +270,38 @@ def test_every_tool_is_valid_python():
         ast.parse(open(f).read(), filename=f)
 
 
-def test_no_packed_fp32_op_sel_form_where_other_waves_run_mfmas(tmp_path):
-    """Round 4: on MI355X `v_pk_mul_f32 ... op_sel:[0,1]` -- a packed fp32 instruction whose low half takes the HIGH word
-    of a source pair -- gave a wrong low half a few times per 1e10 elements whenever other waves of the CU were issuing MFMAs
-    (tools/probes/pk_after_load_probe.hip); the 128-row GEMM family, two workgroups per CU, lost a bit per ~20 forwards to it.  Kernels
-    whose VALU work overlaps other waves' MFMAs must not contain the form: the 128- / 256-row GEMMs, both attention kernels, every
-    scan kernel.  (The large-batch gemm8 kernels hold a few, in epilogues that all eight waves of the CU's only workgroup run together.)"""
+def test_no_packed_fp32_op_sel_form_in_any_kernel(tmp_path):
+    """Round 4 (LABNOTES.md, round 4): on MI355X `v_pk_mul_f32 ... op_sel:[0,1]` -- a packed fp32 instruction whose low half takes the
+    HIGH word of a source pair -- gave a wrong low half a few times per 1e10 elements whenever other waves of the CU were issuing
+    MFMAs (tools/probes/pk_after_load_probe.hip); the 128-row GEMM family, two workgroups per CU, lost a bit per ~20 forwards to
+    it.  Round 5: the form is gone from EVERY kernel of the shipped library, the large-batch gemm8 kernels included (their
+    folded-LayerNorm epilogues broadcast rstd, the high word of a loaded (mean, rstd) pair, through an opaque copy).  The check
+    disassembles the code objects inside libhaconvdr.so itself -- the file the tests and the bench load -- so it cannot pass on
+    stale objects, and it fails (not skips) when the library is missing."""
     import re
     import shutil
     import subprocess
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "haconvdr_amd", "csrc")
-    if not os.path.exists(objdump) or not os.path.exists(os.path.join(csrc, "encoder.o")):
-        pytest.skip("no llvm-objdump / objects (the library was built elsewhere)")
-    seen_kernels = 0
-    for obj in ("encoder.o", "flat_ip.o"):
-        shutil.copy(os.path.join(csrc, obj), tmp_path / obj)
-        subprocess.run([objdump, "--offloading", obj], cwd=tmp_path, check=True, capture_output=True)
-        code = [f for f in os.listdir(tmp_path) if f.startswith(obj + ".") and "gfx950" in f]
-        assert code, os.listdir(tmp_path)
-        dis = subprocess.run([objdump, "-d", code[0]], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
-        name, bad = None, {}
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump in this image")
+    lib = os.path.join(csrc, "libhaconvdr.so")
+    assert os.path.exists(lib), "libhaconvdr.so is not built (python -c 'import __graft_entry__ as g; g.build()')"
+    shutil.copy(lib, tmp_path / "libhaconvdr.so")
+    subprocess.run([objdump, "--offloading", "libhaconvdr.so"], cwd=tmp_path, check=True, capture_output=True)
+    code = sorted(f for f in os.listdir(tmp_path) if f.startswith("libhaconvdr.so.") and "gfx950" in f)
+    assert len(code) == 2, os.listdir(tmp_path)          # encoder.hip and flat_ip.hip
+    seen_kernels, gemm8, bad = 0, 0, {}
+    for c in code:
+        dis = subprocess.run([objdump, "-d", c], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
+        name = None
         for line in dis.splitlines():
             m = re.match(r"^[0-9a-f]+ <(.*)>:", line)
             if m:
                 name = m.group(1)
                 seen_kernels += 1
-            elif name and re.search(r"v_pk_(mul|fma|add)_f32", line) and "op_sel:[" in line and "gemm8_kernel" not in name:
+                gemm8 += "gemm8_kernel" in name
+            elif name and re.search(r"v_pk_(mul|fma|add)_f32", line) and "op_sel:[" in line:
                 bad[name] = bad.get(name, 0) + 1
-        assert not bad, bad
-    assert seen_kernels > 40
+    assert not bad, bad
+    assert seen_kernels > 40 and gemm8 == 6            # three epilogues x two loop forms were looked at
