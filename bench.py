@@ -51,13 +51,21 @@ def parse_args(argv=None):
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--query-len", type=int, default=512, help="padded query length (TopiOCQA: 512, QReCC: 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="only the headline step (profiling runs)")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline step (profiling runs); = --extras none")
+    ap.add_argument("--extras", choices=("none", "verify", "default", "full"), default="default",
+                    help="default: the step's parts, kernel classes, north-star corpus, configs[1] / [3] / [4] shapes (the driver's run: "
+                         "finishes in ~2 min); full: + sustained 30-s loops, the encoder batch sweep and peaked attention; verify: only the "
+                         "north-star corpus step with its N > 1 self-verification; none: the headline step alone")
+    ap.add_argument("--north-star-rows", type=int, default=NORTH_STAR_ROWS, help="tests only: a smaller north-star corpus for rehearsals")
     ap.add_argument("--search-only", action="store_true", help="BASELINE configs[1] style: pre-encoded embeddings, no encoder in the step")
     ap.add_argument("--dump-results", default=None, metavar="NPZ",
                     help="rank 0 writes the last timed step's query embeddings and merged (D, I) to this .npz (tests)")
     ap.add_argument("--spawn-selftest", type=int, default=None, metavar="RC",
                     help="tests only: every rank prints its RANK/WORLD_SIZE and exits (rank 1 with code RC); nothing touches a GPU")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.no_extras:
+        args.extras = "none"
+    return args
 
 
 # ------------------------------------------------------------------------------ N > 1 without a launcher
@@ -173,7 +181,11 @@ def main():
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            # a wedged rank must end the run with a non-zero code instead of hanging the node: the watchdog of the NCCL (= RCCL)
+            # backend aborts the process when a collective has been pending this long; spawn_ranks() then terminates the others
+            import datetime
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev,
+                                    timeout=datetime.timedelta(seconds=int(os.environ.get("HAC_BENCH_NCCL_TIMEOUT_S", "240"))))
 
     from haconvdr_amd import synth
     from haconvdr_amd.encoder import ANCEEncoder
@@ -241,8 +253,25 @@ def main():
         if enc is not None:
             dist.all_gather_into_tensor(allq, torch.zeros((nq_loc, D_EMB), dtype=torch.float32, device=dev))
         warm_keys = torch.zeros((nq, k), dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(torch.empty((world * nq, k), dtype=torch.int64, device=dev), warm_keys)
+        gath_keys = torch.empty((world * nq, k), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(gath_keys, warm_keys)
         sync()
+        # Self-verification of the collective layer (nobody can rehearse the 8-GPU RCCL run): did the backend see N ranks, does an
+        # all-gather deliver every rank's slab in rank order, and what do the step's two collectives cost by themselves
+        ones = torch.ones(1, device=dev, dtype=torch.int64)
+        dist.all_reduce(ones)
+        warm_keys.fill_(rank + 1)
+        dist.all_gather_into_tensor(gath_keys, warm_keys)
+        slabs = gath_keys.view(world, -1)[:, 0].cpu().tolist()
+        emb_probe = torch.zeros((nq_loc, D_EMB), dtype=torch.float32, device=dev)
+        t_ag_emb = max_over_ranks(timed(lambda: dist.all_gather_into_tensor(allq, emb_probe), 10, sync, barrier)) if enc is not None else None
+        t_ag_keys = max_over_ranks(timed(lambda: dist.all_gather_into_tensor(gath_keys, warm_keys), 10, sync, barrier))
+        collective = {"backend": dist.get_backend(), "world": world, "ranks_seen": int(ones.item()),
+                      "allgather_slabs_in_rank_order": slabs == list(range(1, world + 1)),
+                      "allgather_emb_ms": None if t_ag_emb is None else round(t_ag_emb * 1e3, 4), "allgather_emb_bytes_per_rank": nq_loc * D_EMB * 4,
+                      "allgather_keys_ms": round(t_ag_keys * 1e3, 4), "allgather_keys_bytes_per_rank": nq * k * 8,
+                      "devices": f"rank {rank} on cuda:{local_rank} of {torch.cuda.device_count()} visible"}
+        del gath_keys, emb_probe
     for _ in range(args.warmup):
         step()
     index.set_profiling(True)
@@ -390,6 +419,9 @@ def main():
     }
     if world > 1:
         out["like_for_like_n1"] = "extras.cfg4_shard_step.queries_per_sec of the N = 1 line (one 6.75M-row shard, all 1000 queries encoded on that GPU)"
+        out["collective"] = collective
+        if collective["ranks_seen"] != world or not collective["allgather_slabs_in_rank_order"]:
+            out["collective"]["error"] = "the process group did not deliver every rank's contribution in rank order"
     if rehearsal:
         out["rehearsal"] = f"NOT a measurement: {world} ranks share {torch.cuda.device_count()} GPU(s) over gloo (HAC_BENCH_REHEARSAL=1)"
     extras = {}
@@ -400,9 +432,10 @@ def main():
                                            timed_emb.cpu().numpy() if timed_emb is not None else None, enc_plan)
     kept = None
 
-    if not args.no_extras:
+    ns_rows = args.north_star_rows
+    if args.extras != "none":
         # ---- the step's parts, and the same step with the queries' real lengths ------------------------
-        if enc is not None:
+        if enc is not None and args.extras != "verify":
             t_enc = max_over_ranks(timed(lambda: enc(ids_t, mask_t), 3, sync, barrier))
             emb_now = enc(ids_t, mask_t)
             if world > 1:
@@ -440,17 +473,59 @@ def main():
             extras["encoder_kernels"] = {"layer_stack_ms": round(stack, 3), "per_class": per_class,
                                          "note": "one forward of this rank's queries with an event pair around every launch"}
         # ---- the north-star corpus: 10M x 768 over the N GPUs, same step ----------------------------------
-        if rows != NORTH_STAR_ROWS:
-            lo2, hi2 = shard_range(NORTH_STAR_ROWS, rank, world)
+        if rows != ns_rows:
+            lo2, hi2 = shard_range(ns_rows, rank, world)
             idx2 = FlatIPIndex(D_EMB, devices=(local_rank,))
-            fill_index(idx2, lo2, hi2, dev, -(-NORTH_STAR_ROWS // (CFG3_BLOCKS * world)))
+            fill_index(idx2, lo2, hi2, dev, -(-ns_rows // (CFG3_BLOCKS * world)))
             srch2 = ShardedSearcher(idx2, shard_base=lo2)
             t_ns = max_over_ranks(timed(lambda: step(None, srch2), 3, sync, barrier))
             extras["north_star_10M"] = {"queries_per_sec": round(nq / t_ns, 1), "ms_per_step": round(t_ns * 1e3, 3),
-                                        "what": f"same step over a {NORTH_STAR_ROWS}x768 corpus on {world} GPU(s) ({hi2 - lo2} rows per GPU); "
+                                        "what": f"same step over a {ns_rows}x768 corpus on {world} GPU(s) ({hi2 - lo2} rows per GPU); "
                                                 "BASELINE.json north_star target: >= 3000 queries/s on 8 GPUs"}
-            del idx2, srch2
-        if world == 1 and enc is not None and rows == CFG3_ROWS:
+            if world > 1:
+                # Self-verification of the sharded result: the 10M rows regenerate from seeds and fit ONE GPU, so rank 0 searches
+                # them whole with the exact fp32 kernels (split = "0": no prefilter, no collective, no merge) for eight fixed
+                # queries of the step and compares with the merged (D, I) the N-rank step returned for those queries
+                Dn, In = step(None, srch2)
+                qv = last["emb"][:8].clone()
+                sync()
+                barrier()
+                del idx2, srch2
+                verify = None
+                if rank == 0:
+                    idx_all = FlatIPIndex(D_EMB, devices=(local_rank,))
+                    fill_index(idx_all, 0, ns_rows, dev, -(-ns_rows // CFG3_BLOCKS))
+                    idx_all.set_option("split", "0")
+                    Dv, Iv = idx_all.search_tensor(qv, k)
+                    sync()
+                    verify = {"queries": 8, "rows": ns_rows, "referee": "one GPU, exact fp32 kernels (" + idx_all.last_plan().split(" ")[0] + ")",
+                              "ids_equal": bool(torch.equal(Iv, In[:8])), "scores_equal": bool(torch.equal(Dv, Dn[:8]))}
+                    del idx_all
+                barrier()
+                extras["north_star_10M"]["verify"] = verify
+                # the like-for-like anchor of this series, measured on these very GPUs: the FULL step -- all nq queries encoded on
+                # this GPU, searched over this GPU's shard, no collective -- i.e. what the N = 1 line calls cfg4_shard_step
+                if enc is not None and (not args.rows or args.extras == "verify"):
+                    tok_all, _ = synth.token_batch(0x70C, nq, Lq, fixed_len=Lq)
+                    ids_all = torch.from_numpy(tok_all.astype(np.int64)).to(dev)
+                    mask_all = torch.ones_like(ids_all)
+                    from haconvdr_amd.index import keys_to_results
+
+                    def local_step():
+                        return keys_to_results(index.search_keys_tensor(enc(ids_all, mask_all), k, pos_base=lo))
+                    t_loc = timed(local_step, 3, sync)
+                    rate = torch.tensor([nq / t_loc], device=dev, dtype=torch.float64)
+                    rmin, rmax = rate.clone(), rate.clone()
+                    dist.all_reduce(rmin, op=dist.ReduceOp.MIN)
+                    dist.all_reduce(rmax, op=dist.ReduceOp.MAX)
+                    extras["cfg4_shard_step"] = {"queries_per_sec": round(nq / t_loc, 1), "ms_per_step": round(t_loc * 1e3, 3), "rows_per_gpu": n_local,
+                                                 "queries_per_step": nq, "min_over_ranks": round(float(rmin.item()), 1), "max_over_ranks": round(float(rmax.item()), 1),
+                                                 "what": "the N = 1 anchor of this series measured on THIS run's GPUs: every rank encodes all the step's queries and "
+                                                         "searches its own 6.75M-row shard, no collective (rank 0's figure; min / max over the ranks beside it)"}
+                    del ids_all, mask_all
+            else:
+                del idx2, srch2
+        if world == 1 and enc is not None and rows == CFG3_ROWS and args.extras != "verify":
             # BASELINE configs[3] on ONE of its eight ranks, part by part (the 8-GPU run is the driver's): encode 1000 / 8
             # queries, search all 1000 over a 6.75M-row shard.  The two all-gathers between them (3 MB of embeddings, 0.8 MB
             # of packed keys per rank) are not in these figures.
@@ -472,14 +547,18 @@ def main():
                                          "queries_per_step": nq, "what": "like-for-like N = 1 anchor of the N > 1 series (BASELINE configs[3] shard size): "
                                                                          "encode 1000 queries (L = 512) + top-100 over one 6.75M-row shard"}
             del idx4, srch4
-        if world == 1:
+        if world == 1 and args.extras != "verify":
             extras.update(single_gpu_extras(np, torch, synth, FlatIPIndex, enc, index, q_pre, dev, n_local, nq, k, sync))
             if enc is not None and nq >= 1000 and Lq == 512:
-                extras["sustained"] = sustained(np, torch, synth, enc, step, nq, dev, sync)
-                extras["encoder_batch_sweep"] = encoder_batch_sweep(np, torch, synth, enc, dev, sync)
-                extras["attention_peaked"] = attention_peaked(np, torch, synth, enc, ids_t, mask_t, nq, Lq, sync)
+                # the reference's literal call shapes (B = 4 x 512 and the first rows of the sweep) stay in the default line; the
+                # whole sweep, the 30-s sustained loops and the peaked-attention series are `--extras full` (they took the default
+                # run from 113 s to 222 s of the driver's 600-s limit in round 4)
+                extras["encoder_batch_sweep"] = encoder_batch_sweep(np, torch, synth, enc, dev, sync, full=args.extras == "full")
+                if args.extras == "full":
+                    extras["sustained"] = sustained(np, torch, synth, enc, step, nq, dev, sync)
+                    extras["attention_peaked"] = attention_peaked(np, torch, synth, enc, ids_t, mask_t, nq, Lq, sync)
             extras["three_call_protocol"] = three_call_protocol(np, torch, FlatIPIndex, q_pre, dev, k)
-        elif enc is not None:
+        elif enc is not None and args.extras != "verify":
             # BASELINE configs[4] shape on N GPUs: passage encoding is embarrassingly parallel (every rank encodes the blocks it
             # owns, no collective): each rank times 1000 synthetic passages of L = 384, the job rate is the sum over ranks
             Bp, Lp = 1000, 384
@@ -499,11 +578,19 @@ def main():
             psg["mfma_bf16_frac_padded"] = round(12.0 * (14155776.0 * Lp + 4.0 * Lp * Lp * 768.0) * psg["docs_per_sec_padded"] / world / 2.5e15, 4)
             extras["passages_L384"] = psg
 
+    failed = None
     if rank == 0:
         out.update(extras)
         print(json.dumps(out), flush=True)
+        v = (extras.get("north_star_10M") or {}).get("verify")
+        if v is not None and not (v["ids_equal"] and v["scores_equal"]):
+            failed = "the sharded step's merged (D, I) differ from the single-GPU exact search (north_star_10M.verify)"
+        if world > 1 and "error" in out.get("collective", {}):
+            failed = out["collective"]["error"]
     if world > 1:
         dist.destroy_process_group()
+    if failed:
+        raise SystemExit("bench.py: " + failed)       # after the JSON line: the record shows what was measured AND that it is wrong
 
 
 # ------------------------------------------------------------------------------ committed PMC passes (roofline.traffic)
@@ -700,9 +787,20 @@ def cpu_baseline(np, torch, synth, enc, D, I, q_pre, kept, rows, nq, k, Lq, tok,
         got_t = timed_emb[pick]
         cosd_t = 1.0 - (got_t * ref_t).sum(1) / (np.linalg.norm(got_t, axis=1) * np.linalg.norm(ref_t, axis=1))
         res["encode"]["max_1_minus_cos_timed_batch_vs_cpu"] = float(cosd_t.max())
+        # the same check scaled to what these rows can show (tests/parity.py): N(0, 0.02^2) weights put all embeddings close to
+        # one direction, so the raw figure is read against the distance between two DIFFERENT sequences of the pick
+        from tests import parity
+        pm = parity.measure(got_t, ref_t)
         res["encode"]["timed_batch_check"] = {"rows": pick, "one_minus_cos": [float(v) for v in cosd_t], "kernels": enc_plan,
+                                              "inter_sequence_min_1_minus_cos": pm["spread"]["raw_min"],
+                                              "error_over_inter_sequence_distance": pm["raw"] / pm["spread"]["raw_min"],
+                                              "centred_1_minus_cos": pm["centred"], "centred_bound": pm["centred_bound"],
+                                              "relative_l2": pm["rel_l2"], "relative_l2_bound": pm["rel_l2_bound"],
+                                              "passes_fixture_scaled_bounds": bool(parity.embeddings_match(got_t, ref_t)),
+                                              "neighbours_embedding_would_pass": bool(parity.embeddings_match(np.roll(got_t, 1, axis=0), ref_t)),
                                               "what": "embeddings produced INSIDE the timed region (last timed step) vs oracle/ance_oracle.py on the same sequences; "
-                                                      "bar 1e-3 (BASELINE.json north_star)"}
+                                                      "bar 1e-3 (BASELINE.json north_star) and a tenth of the smallest distance between two of these sequences' "
+                                                      "reference embeddings; centred = batch mean of the reference rows removed from both sides"}
     res["value"] = round(1.0 / (t_enc_q + t_search_q), 3)
     res["cores"] = max(omp_threads, torch.get_num_threads())          # the threads actually used (the larger of the two legs)
     res["threads"] = {"search_openmp": omp_threads, "encode_torch": torch.get_num_threads()}
@@ -718,15 +816,17 @@ def enc_flops(B, L):
     return B * (12.0 * (14155776.0 * L + 4.0 * L * L * 768.0) + 2.0 * 768 * 768)
 
 
-def encoder_batch_sweep(np, torch, synth, enc, dev, sync):
+def encoder_batch_sweep(np, torch, synth, enc, dev, sync, full=True):
     """The encoder at the batch shapes the reference itself calls it with: 4 x n_gpu queries per call
     (src/test_HAConvDR_topiocqa.py:173,406), 250 x n_gpu passages (Config/gen_doc_embeddings.toml:14,17), fully padded
     (L = 512 TopiOCQA queries, 256 QReCC queries, 384 passages).  ms = wall clock per forward over back-to-back calls (device
     tensors in and out, no host sync between calls).  Small batches replay a HIP graph (graph=replay); `graph_off_ms` is the
     same shape with plain launches."""
     rows = []
-    for L in (256, 384, 512):
-        for B in (1, 4, 16, 64, 250, 500):
+    # default line: the reference's literal query call (B = 4) at its two lengths, one sequence, and the passage batch; full: the grid
+    shapes = [(L, B) for L in (256, 384, 512) for B in (1, 4, 16, 64, 250, 500)] if full else [(256, 1), (256, 4), (512, 4), (512, 16), (384, 250)]
+    for L, B in shapes:
+        if True:
             tok, _ = synth.token_batch(0x5EE + B + L, B, L, fixed_len=L)
             ids = torch.from_numpy(tok.astype(np.int64)).to(dev)
             mask = torch.ones_like(ids)

@@ -1382,6 +1382,8 @@ struct hac_encoder {
         int ks_out = 1, ks_down = 1;      // the plan of the captured forward (a replay runs no host-side planning)
     };
     std::map<uint64_t, GraphEntry> graphs;
+    hipEvent_t graph_done = nullptr;      // recorded behind every replay on the caller's stream: an exec is destroyed only after it
+    bool graph_done_armed = false;
     GrowBuf ws_gids, ws_gmask, ws_gout;
 };
 
@@ -1452,7 +1454,8 @@ int pick_family(const hac_encoder *e, long rows) {
     return big ? FAM_CLASSIC256 : FAM_CLASSIC128;
 }
 template <typename IT>
-int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, float *out_dev, hipStream_t st, long rows_hint = 0, int family = -1) {
+int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, float *out_dev, hipStream_t st, long rows_hint = 0, int family = -1,
+                long rows_plan = 0) {
     const hac_encoder_config &c = e->cfg;
     const int L32 = (L + SEQ_ALIGN - 1) / SEQ_ALIGN * SEQ_ALIGN;
     const long rows_max = rows_hint > 0 ? std::min<long>(rows_hint, (long)B * L32) : (long)B * L32;
@@ -1494,9 +1497,12 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
     const size_t lds = (size_t)4 * bt * 128 + (size_t)(big ? 8 : 4) * 4096;   // 2 stages + per-wave patches
     // Small batches (128^2 tiles): the two RESID GEMMs have only Mp / 128 x 6 output tiles -- 96 for the reference's 4 x 512 query
     // batch, on 256 CUs -- so their K loop is split until ~1.5 work items per CU exist (slices of at least three k-tiles)
+    // (the split -- i.e. the summation order -- is decided ONCE per hac_encoder_forward* call, from the rows of its first
+    // sub-batch (rows_plan), like the family: a sequence's embedding must not depend on the sub-batch it fell into)
+    const long Mp_plan = rows_plan > 0 ? (rows_plan + MT - 1) / MT * MT : Mp;
     auto pick_ksplit = [&](int K) {
         if (g8 || big || e->ksplit_mode == 0) return 1;
-        const long tiles = (Mp / 128) * (H / 128);
+        const long tiles = (Mp_plan / 128) * (H / 128);
         const int KT = K / 64;
         int S = 1;
         for (int cand : {2, 3, 4, 6, 8, 12, 16}) {
@@ -1703,7 +1709,15 @@ uint64_t ws_signature(const hac_encoder *e) {
         h = (h ^ (uint64_t)(uintptr_t)b->p) * 1099511628211ull;
     return h;
 }
+// (an executable graph may still be running on the stream of the call that replayed it last: wait for that replay's event
+// before destroying anything -- HIP does not document destroying an in-flight exec as safe)
+void graphs_quiesce(hac_encoder *e) {
+    if (e->graph_done_armed) (void)hipEventSynchronize(e->graph_done);
+    e->graph_done_armed = false;
+}
 void drop_graphs(hac_encoder *e) {
+    if (e->graphs.empty()) return;
+    graphs_quiesce(e);
     for (auto &kv : e->graphs) {
         if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
         if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
@@ -1714,7 +1728,7 @@ constexpr size_t GRAPH_MAX_SHAPES = 64;   // captured (B, L, options) shapes kep
 bool graph_eligible(const hac_encoder *e, int B, int L, hipStream_t st) {
     if (e->graph_mode == 0 || e->prof_mask != 0) return false;
     const int L32 = (L + SEQ_ALIGN - 1) / SEQ_ALIGN * SEQ_ALIGN;
-    if ((long)B * L32 > GRAPH_MAX_ROWS) return false;
+    if ((long)B * L32 > GRAPH_MAX_ROWS || (long)B * L32 > e->max_tokens) return false;   // (beyond max_tokens the call is cut into sub-batches)
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;   // the caller captures: plain launches
     return true;
@@ -1726,7 +1740,8 @@ int forward_graph(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, f
     HAC_TRY(e->ws_gmask.reserve(n_in));
     HAC_TRY(e->ws_gout.reserve(n_out));
     const uint64_t key = ((uint64_t)B << 40) | ((uint64_t)L << 24) | ((uint64_t)sizeof(IT) << 16) | ((uint64_t)(e->attn_mode & 1) << 8) |
-                         ((uint64_t)((e->gemm_mode + 1) & 3) << 4) | (uint64_t)(e->g8_split & 15) | ((uint64_t)(e->ksplit_mode & 1) << 12);
+                         ((uint64_t)((e->gemm_mode + 1) & 3) << 4) | (uint64_t)(e->g8_split & 15) | ((uint64_t)(e->ksplit_mode & 1) << 12) |
+                         ((uint64_t)(e->attn_qsplit & 1) << 13) | ((uint64_t)(e->g8_stagger & 1) << 14);
     // (a caller that pads every batch to its own longest sequence can show hundreds of shapes: the cache is bounded, and starting
     // over costs each live shape one plain forward and one capture)
     if (e->graphs.size() >= GRAPH_MAX_SHAPES && e->graphs.find(key) == e->graphs.end()) drop_graphs(e);
@@ -1751,6 +1766,7 @@ int forward_graph(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, f
     } else {
         if (!ge.exec || ge.sig != ws_signature(e)) {
             // (a larger forward in between may have regrown a workspace: the captured launches hold the old pointers)
+            if (ge.exec) graphs_quiesce(e);
             if (ge.exec) (void)hipGraphExecDestroy(ge.exec);
             if (ge.graph) (void)hipGraphDestroy(ge.graph);
             ge.exec = nullptr;
@@ -1771,6 +1787,9 @@ int forward_graph(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, f
             ge.ks_down = e->plan_ks_down;
         }
         HAC_HIP(hipGraphLaunch(ge.exec, st));
+        if (!e->graph_done) HAC_HIP(hipEventCreateWithFlags(&e->graph_done, hipEventDisableTiming));
+        HAC_HIP(hipEventRecord(e->graph_done, st));
+        e->graph_done_armed = true;
         e->plan_gemm = ge.gemm;
         e->plan_rows = ge.rows;
         e->plan_ks_out = ge.ks_out;
@@ -1822,7 +1841,7 @@ int forward_batched(hac_encoder *e, const IT *ids, const IT *mask, int B, int L,
             rows += r;
             ++nb;
         }
-        HAC_TRY(run_forward<IT>(e, ids + (size_t)b0 * L, mask + (size_t)b0 * L, nb, L, out_dev + (size_t)b0 * H, st, rows, family));
+        HAC_TRY(run_forward<IT>(e, ids + (size_t)b0 * L, mask + (size_t)b0 * L, nb, L, out_dev + (size_t)b0 * H, st, rows, family, rows_first));
         b0 += nb;
     }
     return HAC_OK;
@@ -1899,6 +1918,7 @@ void hac_encoder_destroy(hac_encoder *e) {
         if (l.fold) (void)hipFree(l.fold);
     }
     drop_graphs(e);
+    if (e->graph_done) (void)hipEventDestroy(e->graph_done);
     for (GrowBuf *b : {&e->ws_x, &e->ws_xb, &e->ws_q, &e->ws_k, &e->ws_vt, &e->ws_ctx, &e->ws_y, &e->ws_h, &e->ws_seq, &e->ws_ids, &e->ws_mask, &e->ws_out, &e->ws_cls, &e->ws_stats, &e->ws_yb, &e->ws_part, &e->ws_idstats,
                        &e->ws_gids, &e->ws_gmask, &e->ws_gout, &e->ws_ksplit})
         b->release();

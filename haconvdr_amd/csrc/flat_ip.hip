@@ -1126,9 +1126,11 @@ struct DeviceIndex {
         HAC_TRY(ws_err.reserve(16));   // (a new GrowBuf is zero)
         HAC_HIP(hipHostMalloc((void **)&h_err, 16, hipHostMallocDefault));
         h_err[0] = h_err[1] = 0u;
-        HAC_HIP(hipHostMalloc((void **)&h_plan, 16, hipHostMallocDefault));
-        h_plan[0] = h_plan[1] = 0u;
-        HAC_HIP(hipEventCreateWithFlags(&ev_plan, hipEventDisableTiming));
+        HAC_HIP(hipHostMalloc((void **)&h_plan, 8 * PLAN_RING, hipHostMallocDefault));
+        for (int i = 0; i < PLAN_RING; ++i) {
+            h_plan[2 * i] = h_plan[2 * i + 1] = 0u;
+            HAC_HIP(hipEventCreateWithFlags(&ev_plan[i], hipEventDisableTiming));
+        }
         static bool attr_done[64] = {false};
         if (device < 64 && !attr_done[device]) {
             HAC_HIP(hipFuncSetAttribute((const void *)scan16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1166,7 +1168,8 @@ struct DeviceIndex {
         if (h_fb) (void)hipHostFree(h_fb);
         if (h_err) (void)hipHostFree(h_err);
         if (h_plan) (void)hipHostFree(h_plan);
-        if (ev_plan) (void)hipEventDestroy(ev_plan);
+        for (hipEvent_t ev : ev_plan)
+            if (ev) (void)hipEventDestroy(ev);
         for (int i = 0; i < 2; ++i) {
             if (h_stage[i]) (void)hipHostFree(h_stage[i]);
             if (stage_ev[i]) (void)hipEventDestroy(stage_ev[i]);
@@ -1422,34 +1425,62 @@ struct DeviceIndex {
     char last_plan[320] = "none";
     // a device-decided prefilter search leaves its fallback count and err / bound on the device: plan() completes the text
     char plan_head[200] = "";
-    bool plan_pending = false;
-    int64_t plan_nq = 0;
     // The status words of a device-decided search reach the host through a pinned copy enqueued on the CALLER's stream and
     // a library-owned event behind it: plan() waits for that event only -- never for the caller's stream, which may be gone
-    // or capturing by the time someone asks.
-    hipEvent_t ev_plan = nullptr;
-    u32 *h_plan = nullptr;     // pinned [2]
-    // (called at the start of the next device-decided search too, so that the fallback count of a search nobody polled is
-    // not lost as long as it had completed by then)
-    void plan_collect(bool wait) {
-        if (!plan_pending || !ev_plan) return;
-        hipError_t e = wait ? hipEventSynchronize(ev_plan) : hipEventQuery(ev_plan);
+    // or capturing by the time someone asks.  Back-to-back device-decided searches each take their own (words, event) slot of
+    // a small ring (with one slot, a search issued before the previous one had completed overwrote its words and
+    // that search's fallback count never reached split_fallback_queries); when every slot is pending the oldest is waited for.
+    static constexpr int PLAN_RING = 8;
+    hipEvent_t ev_plan[PLAN_RING] = {};
+    u32 *h_plan = nullptr;     // pinned [PLAN_RING][2]: (queries that fell back, max err / bound as float bits)
+    bool slot_pending[PLAN_RING] = {};
+    int64_t slot_nq[PLAN_RING] = {};
+    int plan_head_slot = 0;    // next slot to hand out; pending slots are the ones before it, oldest first
+    int plan_text_slot = -1;   // the slot whose search last_plan describes (-1: last_plan is complete as it stands)
+    // true when slot i has been retired (its count added); wait = block until it has
+    bool plan_retire(int i, bool wait) {
+        if (!slot_pending[i]) return true;
+        hipError_t e = wait ? hipEventSynchronize(ev_plan[i]) : hipEventQuery(ev_plan[i]);
         if (e == hipErrorNotReady) {
             (void)hipGetLastError();
-            return;
+            return false;
         }
         // (an error here = the search was captured into a graph: the event was never recorded for real and cannot be waited
         // for; the pinned words then are those of the last replay that has completed -- synchronize the stream you replay on)
         if (e != hipSuccess) (void)hipGetLastError();
-        float maxratio;
-        std::memcpy(&maxratio, &h_plan[1], 4);
-        snprintf(last_plan, sizeof last_plan, "%s fallback=%u/%lld err/bound=%.3g decided=device%s", plan_head, h_plan[0], (long long)plan_nq, (double)maxratio,
-                 e == hipSuccess ? "" : " (captured: as of the last completed replay)");
-        split_fallback_queries += h_plan[0];
-        plan_pending = false;
+        if (i == plan_text_slot) {
+            float maxratio;
+            std::memcpy(&maxratio, &h_plan[2 * i + 1], 4);
+            snprintf(last_plan, sizeof last_plan, "%s fallback=%u/%lld err/bound=%.3g decided=device%s", plan_head, h_plan[2 * i], (long long)slot_nq[i],
+                     (double)maxratio, e == hipSuccess ? "" : " (captured: as of the last completed replay)");
+            plan_text_slot = -1;
+        }
+        split_fallback_queries += h_plan[2 * i];
+        slot_pending[i] = false;
+        return true;
+    }
+    // (called at the start of the next device-decided search too, so that the fallback count of a search nobody polled is
+    // collected as soon as it has completed)
+    void plan_collect(bool wait) {
+        for (int n = 0; n < PLAN_RING; ++n) {
+            const int i = (plan_head_slot + n) % PLAN_RING;   // oldest first
+            if (!plan_retire(i, wait)) break;                 // in stream order: a younger one cannot be ready either
+        }
+    }
+    // a slot for the search being enqueued
+    int plan_slot() {
+        const int i = plan_head_slot;
+        if (slot_pending[i]) (void)plan_retire(i, true);      // the ring is full: the oldest search must finish first
+        plan_head_slot = (i + 1) % PLAN_RING;
+        return i;
+    }
+    bool plan_pending() const {
+        for (bool b : slot_pending)
+            if (b) return true;
+        return false;
     }
     const char *plan() {
-        if (plan_pending) {
+        if (plan_pending()) {
             DeviceGuard g(device);
             plan_collect(true);
         }
@@ -1640,7 +1671,7 @@ struct DeviceIndex {
         else
             snprintf(last_plan, sizeof last_plan, "scan16_kernel<W=%d> grid=(%d,%d) QT=%d C=%d lds=%zu seed=%d", SCAN_WAVES, pl.P,
                      pl.n_qtiles, pl.QT, pl.C, pl.lds_scan, thr_init ? 1 : 0);
-        if (!nq_dev) plan_pending = false;
+        if (!nq_dev) plan_text_slot = -1;   // (last_plan is this search's text; older device-decided searches still deliver their counts)
         HAC_TRY(run_scan(pl, q_dev, nq, k, 0, 1, G, thr_init, pos_base, pl.P, st, profiling, nq_dev));
         // the workgroups' survivors sit densely per query: radix select of the k best, one sort of k keys
         const int np2 = (int)next_pow2((u32)k);
@@ -1863,10 +1894,12 @@ struct DeviceIndex {
             snprintf(plan_head, sizeof plan_head, "split: scanh_kernel<%d> grid=(%ld,%d) NQ=%d K2=%d chunks=%d lds=%zu seed=%d passes=%d", terms, P_last,
                      n_qtiles_last, SH_NQ, K2, n_chunks, lds, seeded, passes_last);
             snprintf(last_plan, sizeof last_plan, "%s fallback=device-side/%lld", plan_head, (long long)nq);
-            HAC_HIP(hipMemcpyAsync(h_plan, ws_stat.p, 8, hipMemcpyDeviceToHost, st));
-            HAC_HIP(hipEventRecord(ev_plan, st));
-            plan_pending = true;
-            plan_nq = nq;
+            const int slot = plan_slot();
+            HAC_HIP(hipMemcpyAsync(h_plan + 2 * slot, ws_stat.p, 8, hipMemcpyDeviceToHost, st));
+            HAC_HIP(hipEventRecord(ev_plan[slot], st));
+            slot_pending[slot] = true;
+            slot_nq[slot] = nq;
+            plan_text_slot = slot;
             return HAC_OK;
         }
         HAC_HIP(hipMemcpyAsync(h_fb, ws_stat.p, 8, hipMemcpyDeviceToHost, st));
@@ -1879,7 +1912,7 @@ struct DeviceIndex {
         snprintf(plan_here, sizeof plan_here, "split: scanh_kernel<%d> grid=(%ld,%d) NQ=%d K2=%d chunks=%d lds=%zu seed=%d passes=%d fallback=%u/%lld err/bound=%.3g",
                  terms, P_last, n_qtiles_last, SH_NQ, K2, n_chunks, lds, seeded, passes_last, nfail, (long long)nq, (double)maxratio);
         std::memcpy(last_plan, plan_here, sizeof last_plan);
-        plan_pending = false;
+        plan_text_slot = -1;
         if (nfail == 0) return HAC_OK;
 
         // certificate failed for some queries: the next level decides those
@@ -2231,10 +2264,18 @@ int hac_index_search(hac_index *idx, const float *q, int64_t nq, int k, float *D
     std::memcpy(I, hp, (size_t)nq * k * 8);
     std::memcpy(D, hp + (size_t)nq * k * 8, (size_t)nq * k * 4);
     // a scan workgroup that ran into its pass bound: the results are delivered (the affected lists EMPTY), the call says so
+    // (every shard's words are read and cleared before returning: a word left set would be blamed on a later search)
+    int rc_all = HAC_OK;
+    std::string msg_all;
     for (auto *s : idx->shards) {
         DeviceGuard gs(s->device);
-        HAC_TRY(s->check_err(s->stream));
+        const int rc = s->check_err(s->stream);
+        if (rc != HAC_OK && rc_all == HAC_OK) {
+            rc_all = rc;
+            msg_all = last_error_slot();
+        }
     }
+    if (rc_all != HAC_OK) return fail(rc_all, "%s", msg_all.c_str());
     return HAC_OK;
 }
 
@@ -2243,8 +2284,18 @@ int hac_index_last_status(hac_index *idx) {
     for (auto *s : idx->shards) {
         DeviceGuard g(s->device);
         if (!g.ok) return fail(HAC_ERR_HIP, "cannot select HIP device %d", s->device);
-        HAC_TRY(s->fetch_err(s->stream));
     }
+    int rc_all = HAC_OK;
+    std::string msg_all;
+    for (auto *s : idx->shards) {   // every shard's word is read and cleared, the first failure is the one reported
+        DeviceGuard g(s->device);
+        const int rc = s->fetch_err(s->stream);
+        if (rc != HAC_OK && rc_all == HAC_OK) {
+            rc_all = rc;
+            msg_all = last_error_slot();
+        }
+    }
+    if (rc_all != HAC_OK) return fail(rc_all, "%s", msg_all.c_str());
     return HAC_OK;
 }
 

@@ -17,7 +17,7 @@ import numpy as np
 
 CONTRACT = 1e-3      # BASELINE.json north_star: embedding cosines within 1e-3 of the reference CPU path
 FRACTION = 0.1       # of the fixture's minimum inter-sequence distance
-REL_L2 = 0.25        # of the row's distance from the batch mean
+REL_L2 = 0.35        # of the row's distance from the batch mean: a quarter of what another sequence's embedding scores (~ sqrt 2)
 
 
 def one_minus_cos(a, b):

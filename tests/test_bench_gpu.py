@@ -19,13 +19,23 @@ def test_bench_two_rank_rehearsal_matches_single_process(tmp_path):
     dump = str(tmp_path / "step.npz")
     env = dict(os.environ, HAC_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "2000000", "--steps", "2", "--warmup", "1",
-           "--no-cpu-baseline", "--no-extras", "--dump-results", dump]
+           "--no-cpu-baseline", "--extras", "verify", "--north-star-rows", "1500000", "--dump-results", dump]
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     js = json.loads(lines[0])
     assert js["n_gpus"] == 2 and js["steps"] == 2 and js["warmup"] == 1 and js["scaling"] == "weak" and "rehearsal" in js
+    # the N > 1 line verifies itself (round 5: the first real 8-GPU run cannot be rehearsed): the backend saw both ranks, the
+    # all-gather delivers the slabs in rank order, both collectives are timed, the sharded north-star step equals a single-GPU
+    # exact search on eight queries, and the like-for-like anchor's VALUE is in the line
+    c = js["collective"]
+    assert c["backend"] == "gloo" and c["world"] == 2 and c["ranks_seen"] == 2 and c["allgather_slabs_in_rank_order"] is True and "error" not in c
+    assert c["allgather_emb_ms"] > 0 and c["allgather_keys_ms"] > 0 and c["allgather_keys_bytes_per_rank"] == 1000 * 100 * 8
+    v = js["north_star_10M"]["verify"]
+    assert v["queries"] == 8 and v["rows"] == 1_500_000 and v["ids_equal"] is True and v["scores_equal"] is True and "scan" in v["referee"]
+    a = js["cfg4_shard_step"]
+    assert a["queries_per_sec"] > 0 and a["min_over_ranks"] <= a["queries_per_sec"] <= a["max_over_ranks"] * 1.0001 and a["rows_per_gpu"] == 1_000_000
     assert js["config"]["corpus_rows"] == 2_000_000 and js["config"]["rows_per_gpu"] == 1_000_000
     assert js["value"] > 0 and abs(js["value"] - 1000 / (js["ms_per_step"] * 1e-3)) < 1e-3 * js["value"]
     g = np.load(dump)
@@ -62,6 +72,9 @@ def test_bench_four_rank_rehearsal_with_a_query_count_the_ranks_do_not_divide(tm
     assert len(lines) == 1, p.stdout[-2000:]
     js = json.loads(lines[0])
     assert js["n_gpus"] == 4 and "rehearsal" in js and js["config"]["per_gpu_rows"] == 300_000 and "like_for_like_n1" in js
+    c = js["collective"]
+    assert c["world"] == 4 and c["ranks_seen"] == 4 and c["allgather_slabs_in_rank_order"] is True and "error" not in c
+    assert c["allgather_emb_bytes_per_rank"] == 251 * 768 * 4 and c["allgather_keys_bytes_per_rank"] == 1001 * 100 * 8
     g = np.load(dump)
     assert g["emb"].shape == (1001, 768) and g["I"].shape == (1001, 100)
     sys.path.insert(0, ROOT)

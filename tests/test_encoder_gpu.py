@@ -10,23 +10,23 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "encoder_*.npz")))
-COS_TOL = 1e-3          # the contract
-COS_EXPECT = 2e-4       # what bf16 GEMMs + fp32 residual/LN/softmax actually deliver (2e-5..1e-4)
+COS_TOL = 1e-3          # the contract (BASELINE.json north_star)
+COS_EXPECT = 2e-4       # kernel-vs-kernel agreement on N(0, 0.02^2) weights (both sides bf16)
 _SD, _ENC = {}, {}
 
 
-def state_dict(n_layers):
+def state_dict(n_layers, mstd=0.02):
     from haconvdr_amd import synth
-    if n_layers not in _SD:
-        _SD[n_layers] = synth.ance_state_dict(0xA11CE, n_layers)
-    return _SD[n_layers]
+    if (n_layers, mstd) not in _SD:
+        _SD[(n_layers, mstd)] = synth.ance_state_dict(0xA11CE, n_layers, layer_matrix_std=mstd)
+    return _SD[(n_layers, mstd)]
 
 
-def encoder(n_layers):
+def encoder(n_layers, mstd=0.02):
     from haconvdr_amd.encoder import ANCEEncoder
-    if n_layers not in _ENC:
-        _ENC[n_layers] = ANCEEncoder.from_state_dict(state_dict(n_layers))
-    return _ENC[n_layers]
+    if (n_layers, mstd) not in _ENC:
+        _ENC[(n_layers, mstd)] = ANCEEncoder.from_state_dict(state_dict(n_layers, mstd))
+    return _ENC[(n_layers, mstd)]
 
 
 def one_minus_cos(a, b):
@@ -34,36 +34,89 @@ def one_minus_cos(a, b):
     return 1.0 - (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
 
 
-@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[8:-4] for p in GOLD])
-def test_encoder_vs_reference_golden(path):
-    g = np.load(path)
-    enc = encoder(int(g["n_layers"]))
-    out = enc(g["ids"].astype(np.int32), g["mask"].astype(np.int32))
-    ref = g["ref_out"]
-    assert out.shape == ref.shape and out.dtype == np.float32
-    d = one_minus_cos(out, ref)
-    assert np.all(d < COS_TOL), d
-    assert np.all(d < COS_EXPECT), d
-    # LayerNorm'd outputs of norm ~27.7: elementwise agreement too
-    assert np.abs(out - ref).max() < 0.25
+def _plan(enc):
+    return dict(kv.split("=") for kv in enc.last_plan().split())
 
 
+# Goldens = outputs of the reference's models.ANCE.  Every assert is scaled to the fixture (tests/parity.py): raw 1-cos at most
+# a tenth of the smallest distance between two DIFFERENT sequences of the fixture (and never above the 1e-3 contract), the
+# same with the batch mean removed, relative L2 against the row's distance from the batch mean, and a negative control -- the
+# same embeddings handed to the neighbouring sequences must fail.  Measured (tools/parity_survey.py, round 5): N(0, 0.02^2)
+# fixtures 1.7e-6 .. 9.8e-6 (classic kernels) / 6.4e-6 .. 3.6e-5 (gemm8) against rows 1.2e-4 .. 1.8e-3 apart; content-sensitive
+# fixtures ("sens") 8.3e-5 .. 4.0e-4 against rows 0.021 .. 0.10 apart.
+
+
+@pytest.mark.parametrize("gemm", ["auto", "classic", "8phase"])
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[8:-4] for p in GOLD])
-def test_encoder_large_batch_kernels_vs_reference_golden(path):
-    """The large-batch path (gemm8.inc: ping-pong GEMM, LayerNorms folded into the consuming weights, no LayerNorm
-    passes) forced onto the golden inputs: same bar as the classic kernels."""
-    g = np.load(path)
-    enc = encoder(int(g["n_layers"]))
-    enc.set_option("gemm", "8phase")
+def test_encoder_vs_reference_golden(path, gemm):
+    """Every fixture through the automatic routing and through each GEMM family forced (gemm8.inc: ping-pong GEMM,
+    LayerNorms folded into the consuming weights, bf16 residual stream; classic: 128- / 256-row tiles, fp32 residual)."""
+    from tests import parity
+    from tests.golden.make_golden_encoder import load_case
+    name = os.path.basename(path)[8:-4]
+    ids, mask, ref, n_layers, mstd = load_case(path)
+    enc = encoder(n_layers, mstd)
+    enc.set_option("gemm", gemm)
     try:
-        out = enc(g["ids"].astype(np.int32), g["mask"].astype(np.int32))
+        out = enc(ids, mask)
+        plan = _plan(enc)
     finally:
         enc.set_option("gemm", "auto")
-    ref = g["ref_out"]
-    d = one_minus_cos(out, ref)
-    assert np.all(d < COS_TOL), d
-    assert np.all(d < COS_EXPECT), d
-    assert np.abs(out - ref).max() < 0.25
+    assert out.shape == ref.shape and out.dtype == np.float32
+    if gemm == "8phase" or (gemm == "auto" and len(ids) >= 320):
+        assert plan["gemm"] == "gemm8", plan             # the 320 x 512 fixture is auto-routed through the large-batch family
+    if gemm == "classic":
+        assert plan["gemm"].startswith("classic"), plan
+    m = parity.assert_embeddings_match(out, ref, what=(name, gemm))
+    parity.assert_negative_control(out, ref)
+    assert m["raw"] < COS_TOL and m["raw_bound"] <= COS_TOL
+    # LayerNorm'd outputs of norm ~27.7: elementwise agreement too
+    assert np.abs(out - ref).max() < (0.25 if mstd == 0.02 else 1.0)
+
+
+def test_retrieval_from_gpu_embeddings_matches_retrieval_from_reference_embeddings():
+    """What the embeddings are FOR: top-100 over a 100k-row synthetic corpus from the GPU's embeddings of the 320 x 512
+    fixture (auto-routed: gemm8 + streaming attention) against top-100 from the reference's embeddings of the same
+    sequences, both through the exact search of this library.  Lists may differ only where the measured score noise
+    explains it: a row may enter or leave only if its score is within 6 sigma of the k-th score (sigma = |out - ref|, the
+    standard deviation of (out - ref) . x for unit-variance corpus rows), the number of such changes is bounded by the
+    number of corpus rows inside that band, and the same embeddings handed to the neighbouring queries retrieve something
+    else entirely."""
+    from haconvdr_amd import synth
+    from haconvdr_amd.index import FlatIPIndex
+    from tests.golden.make_golden_encoder import load_case
+    path = [p for p in GOLD if "l12_sens_big320" in p][0]
+    ids, mask, ref, n_layers, mstd = load_case(path)
+    enc = encoder(n_layers, mstd)
+    out = enc(ids, mask)
+    assert _plan(enc)["gemm"] == "gemm8"
+    N, K = 100_000, 100
+    x = synth.embeddings(0xC0DE5, N)
+    idx = FlatIPIndex(768, devices=(0,))
+    idx.add(x)
+    Dg, Ig = idx.search(out, K)
+    Dr, Ir = idx.search(ref, K)
+    Dn, In = idx.search(np.roll(out, 1, axis=0), K)         # negative control: every query gets its neighbour's embedding
+    sr = ref.astype(np.float64) @ x.astype(np.float64).T    # [320, N] reference scores
+    sigma = np.linalg.norm(out.astype(np.float64) - ref.astype(np.float64), axis=1)
+    overlap, overlap_neg, worst = [], [], 0.0
+    for qi in range(len(ref)):
+        g, r = set(Ig[qi].tolist()), set(Ir[qi].tolist())
+        overlap.append(len(g & r))
+        overlap_neg.append(len(set(In[qi].tolist()) & r))
+        kth = float(Dr[qi, K - 1])
+        band = 6.0 * sigma[qi] + 1e-3
+        moved = (g - r) | (r - g)
+        for row in moved:                                   # entered or left: its reference score sits at the boundary
+            worst = max(worst, abs(sr[qi, row] - kth) / band)
+            assert abs(sr[qi, row] - kth) <= band, (qi, row, sr[qi, row], kth, band)
+        in_band = int((np.abs(sr[qi] - kth) <= band).sum())
+        assert len(g - r) <= in_band, (qi, len(g - r), in_band)
+    overlap, overlap_neg = np.array(overlap), np.array(overlap_neg)
+    assert overlap.mean() >= 90 and overlap.min() >= 75, (overlap.mean(), overlap.min())
+    assert overlap_neg.mean() <= 50, overlap_neg.mean()
+    print(f"retrieval: mean overlap {overlap.mean():.1f}/100 (min {overlap.min()}), neighbour's embedding {overlap_neg.mean():.1f}/100, "
+          f"sigma {sigma.mean():.3f}, worst moved row at {worst:.2f} of the 6-sigma band")
 
 
 def test_large_batch_kernels_agree_with_classic_on_every_row_and_are_deterministic():
@@ -373,7 +426,8 @@ _SD12 = {}
 def _sd12():
     from haconvdr_amd import synth
     if "sd" not in _SD12:
-        _SD12["sd"] = synth.ance_state_dict(0xA11CE, 12)
+        # content-sensitive weights (synth.ance_state_dict): the oracle's rows are >= 0.02 apart, so the bounds below discriminate
+        _SD12["sd"] = synth.ance_state_dict(0xA11CE, 12, layer_matrix_std=0.08)
     return _SD12["sd"]
 
 
@@ -382,10 +436,6 @@ def _enc12():
     if "enc" not in _SD12:
         _SD12["enc"] = ANCEEncoder.from_state_dict(_sd12())
     return _SD12["enc"]
-
-
-def _plan(enc):
-    return dict(kv.split("=") for kv in enc.last_plan().split())
 
 
 def test_timed_shape_auto_routed_vs_oracle():
@@ -402,8 +452,9 @@ def test_timed_shape_auto_routed_vs_oracle():
     assert np.isfinite(out).all()
     pick = [0, 1, 127, 128, 255, 319]
     ref = ance_oracle.ance_forward(_sd12(), ids[pick], mask[pick])
-    d = one_minus_cos(out[pick], ref)
-    assert d.max() < COS_TOL and d.max() < COS_EXPECT, d
+    from tests import parity
+    parity.assert_embeddings_match(out[pick], ref)
+    parity.assert_negative_control(out[pick], ref)
 
 
 def test_cfg5_shape_varlen_auto_routed_vs_oracle():
@@ -425,8 +476,9 @@ def test_cfg5_shape_varlen_auto_routed_vs_oracle():
     assert np.isfinite(out).all()
     pick = [0, 499, 999, int(np.argmin(lens)), int(np.argmax(lens)), 250]
     ref = ance_oracle.ance_forward(_sd12(), tok[pick], mask[pick])
-    d = one_minus_cos(out[pick], ref)
-    assert d.max() < COS_TOL and d.max() < COS_EXPECT, d
+    from tests import parity
+    parity.assert_embeddings_match(out[pick], ref)
+    parity.assert_negative_control(out[pick], ref)
 
 
 def test_two_sub_batches_auto_routed_vs_oracle_and_small_tail():
@@ -449,8 +501,9 @@ def test_two_sub_batches_auto_routed_vs_oracle_and_small_tail():
     assert plan["gemm"] == "gemm8" and plan["sub_batches"] == "2", plan
     pick = [0, 511, 512, 519]
     ref = ance_oracle.ance_forward(_sd12(), ids[pick], mask[pick])
-    d = one_minus_cos(out[pick], ref)
-    assert d.max() < COS_TOL and d.max() < COS_EXPECT, d
+    from tests import parity
+    parity.assert_embeddings_match(out[pick], ref)
+    parity.assert_negative_control(out[pick], ref)
     order = np.r_[512:520, 0:312]                     # the tail's sequences first, inside one 320-sequence (gemm8) batch
     again = enc(ids[order], mask[order])
     assert _plan(enc)["gemm"] == "gemm8" and _plan(enc)["sub_batches"] == "1"

@@ -280,6 +280,14 @@ def test_full_size_cfg2_properties(oracle):
     q = (q - q.mean(1, keepdim=True)) / q.std(1, unbiased=False, keepdim=True)
     D, I = idx.search_tensor(q, K)
     torch.cuda.synchronize()
+    assert idx.last_plan().startswith("split:")
+    # (0) the exact fp32 kernels as referee on ALL 1000 queries (the CPU oracle below anchors eight of them)
+    idx.set_option("split", "0")
+    Dx, Ix = idx.search_tensor(q, K)
+    torch.cuda.synchronize()
+    assert idx.last_plan().startswith("scanq")
+    idx.set_option("split", "auto")
+    assert torch.equal(Ix, I) and torch.equal(Dx, D)
     # (a) sorted, in range, no duplicates
     assert bool((D[:, :-1] >= D[:, 1:]).all()) and int(I.min()) >= 0 and int(I.max()) < N
     assert all(len(set(r)) == K for r in I[:50].cpu().tolist())
@@ -435,10 +443,13 @@ def test_cfg3_full_residency_25m_rows(oracle):
     D16, I16 = idx.search_tensor(q[:16], K)
     assert idx.last_plan().startswith("scan16")
     assert torch.equal(I16, I[:16]) and torch.equal(D16, D[:16])
+    # full-width referee: the exact fp32 kernels (oracle-pinned above and in every small test) answer ALL 1000 queries;
+    # the prefilter path must agree with them bit for bit on every one, not only on the four the CPU oracle ran
     idx.set_option("split", "0")
-    D64, I64 = idx.search_tensor(q[:64], K)
+    Dx, Ix = idx.search_tensor(q, K)
+    torch.cuda.synchronize()
     assert idx.last_plan().startswith("scanq")
-    assert torch.equal(I64, I[:64]) and torch.equal(D64, D[:64])
+    assert torch.equal(Ix, I) and torch.equal(Dx, D)
 
 
 def test_cfg4_shard_under_an_nccl_group(oracle):
@@ -479,6 +490,10 @@ def test_cfg4_shard_under_an_nccl_group(oracle):
     np.testing.assert_array_equal(D[sel].cpu().numpy(), oD)
     D1, I1 = ShardedSearcher(idx, shard_base=lo).search(q, 100)      # no process group: same answer
     assert torch.equal(I1, I) and torch.equal(D1, D)
+    idx.set_option("split", "0")                                     # the exact kernels as referee on all 1000 queries
+    Dx, Ix = ShardedSearcher(idx, shard_base=lo).search(q, 100)
+    assert idx.last_plan().startswith("scanq")
+    assert torch.equal(Ix, I) and torch.equal(Dx, D)
 
 
 @pytest.mark.parametrize("world", [2, 3])
