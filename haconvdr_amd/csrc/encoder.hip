@@ -1385,6 +1385,7 @@ struct hac_encoder {
     hipEvent_t graph_done = nullptr;      // recorded behind every replay on the caller's stream: an exec is destroyed only after it
     bool graph_done_armed = false;
     GrowBuf ws_gids, ws_gmask, ws_gout;
+    GrowBuf ws_identgb;                   // [2][768]: gamma = 1, beta = 0
 };
 
 namespace {
@@ -1540,6 +1541,12 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
         yAb = (bf16 *)e->ws_yb.p;
         part = (float2 *)e->ws_part.p;
         idstats = (float2 *)e->ws_idstats.p;
+        if (!e->ws_identgb.p) {   // gamma = 1 | beta = 0: residual rows that are final (layer 0's embedding rows) take the same epilogue
+            HAC_TRY(e->ws_identgb.reserve((size_t)2 * H * 4));
+            std::vector<float> gb((size_t)2 * H, 0.f);
+            std::fill(gb.begin(), gb.begin() + H, 1.f);
+            HAC_HIP(hipMemcpy(e->ws_identgb.p, gb.data(), gb.size() * 4, hipMemcpyHostToDevice));
+        }
     }
     HAC_TRY(prof_begin(e, 0, st));
     // compact buffers of the CLS-only tail of the last layer
@@ -1622,7 +1629,9 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
         if (!last && g8) {
             // attention output projection + residual -> yA (bf16) and row-sum partials of its fp32 values -> (mean, rstd)
             g8a.A = ctx; g8a.W = w.wo; g8a.N = H; g8a.K = H; g8a.cvec = w.bo; g8a.resid = xb; g8a.yb = yAb; g8a.part = part;
-            g8a.rstats = defer_in ? statsF : nullptr; g8a.rgamma = ln2g_prev; g8a.rbeta = ln2b_prev;
+            g8a.rstats = defer_in ? statsF : idstats;
+            g8a.rgamma = defer_in ? ln2g_prev : (const float *)e->ws_identgb.p;
+            g8a.rbeta = defer_in ? ln2b_prev : (const float *)e->ws_identgb.p + H;
             HAC_TRY(prof_begin(e, 1 + HAC_ENC_CLASS_OUTPROJ, st));
             stagger8(H, 0, 8);
             launch8(epi_resid, 1);
@@ -1920,7 +1929,7 @@ void hac_encoder_destroy(hac_encoder *e) {
     drop_graphs(e);
     if (e->graph_done) (void)hipEventDestroy(e->graph_done);
     for (GrowBuf *b : {&e->ws_x, &e->ws_xb, &e->ws_q, &e->ws_k, &e->ws_vt, &e->ws_ctx, &e->ws_y, &e->ws_h, &e->ws_seq, &e->ws_ids, &e->ws_mask, &e->ws_out, &e->ws_cls, &e->ws_stats, &e->ws_yb, &e->ws_part, &e->ws_idstats,
-                       &e->ws_gids, &e->ws_gmask, &e->ws_gout, &e->ws_ksplit})
+                       &e->ws_gids, &e->ws_gmask, &e->ws_gout, &e->ws_ksplit, &e->ws_identgb})
         b->release();
     if (e->h_pin) (void)hipHostFree(e->h_pin);
     if (e->h_len) (void)hipHostFree(e->h_len);

@@ -3,6 +3,8 @@
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 [-DG8_STAMP] [-DG8_NO_EPI] tools/probes/gemm8_probe.hip -o gemm8_probe
 #include "../../haconvdr_amd/csrc/encoder.hip"
 #include <cstdio>
+#include <cstring>
+#include <cmath>
 #include <vector>
 #include <random>
 #define CK(x) do{hipError_t e_=(x); if(e_!=hipSuccess){printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} }while(0)
@@ -42,6 +44,14 @@ int main(){
   CK(hipMalloc(&y,(size_t)M*768*4)); CK(hipMalloc(&resid,(size_t)M*768*4)); CK(hipMemset(resid,0,(size_t)M*768*4));
   CK(hipMalloc(&stats,(size_t)M*8)); CK(hipMalloc(&part,(size_t)M*12*8));
   fill_identity_stats_kernel<<<(M+255)/256,256>>>(stats,(size_t)M); CK(hipDeviceSynchronize());
+  if (getenv("G8_RANDOM_EPI")) {   // a correctness run: random residual rows, row statistics and column vectors (the timing runs keep zeros)
+    CK(hipMemcpy(yb2, Apool, (size_t)std::min(poolA, (size_t)M*768)*2, hipMemcpyDeviceToDevice));
+    for (size_t off = poolA; off < (size_t)M*768; off += poolA) CK(hipMemcpy(yb2+off, Apool, std::min(poolA,(size_t)M*768-off)*2, hipMemcpyDeviceToDevice));
+    std::vector<float> hs((size_t)M*2), hv(3072*4); std::uniform_real_distribution<float> ud(0.5f, 1.5f);
+    for (size_t i = 0; i < (size_t)M; ++i) { hs[2*i] = nd(rng)*0.3f; hs[2*i+1] = ud(rng); }
+    for (auto &v : hv) v = nd(rng)*0.5f;
+    CK(hipMemcpy(stats, hs.data(), hs.size()*4, hipMemcpyHostToDevice)); CK(hipMemcpy(vec, hv.data(), hv.size()*4, hipMemcpyHostToDevice));
+  }
   Gemm8Args g{}; g.n_groups=1; g.A=A; g.W=W; g.total_rows=total; g.astats=stats; g.wsum=vec; g.cvec=vec+3072; g.q=q; g.k=k; g.v16=vt; g.resid=yb2; g.rstats=stats; g.rgamma=vec+6144; g.rbeta=vec+9216; g.yb=yb; g.part=part; g.h=h;
   struct Cfg{const char* name; int N,K,epi;};
   Cfg cfgs[] = {{"QKV   N=2304 K=768 ",2304,768,EPI8_QKV},{"OUT   N=768  K=768 ",768,768,EPI8_RESID},{"FFN1  N=3072 K=768 ",3072,768,EPI8_GELU},{"FFN2  N=768  K=3072",768,3072,EPI8_RESID}};
@@ -63,8 +73,11 @@ int main(){
       CK(hipMemset(out, 0xff, nb));
       if(c.epi==EPI8_QKV) gemm8_kernel<EPI8_QKV,true><<<GRID,512,163840>>>(g); if(c.epi==EPI8_RESID) gemm8_kernel<EPI8_RESID,true><<<GRID,512,163840>>>(g); if(c.epi==EPI8_GELU) gemm8_kernel<EPI8_GELU,true><<<GRID,512,163840>>>(g);
       CK(hipDeviceSynchronize()); CK(hipMemcpy(b.data(), out, nb, hipMemcpyDeviceToHost));
-      size_t diff = 0; for (size_t i = 0; i < a.size(); ++i) diff += a[i] != b[i];
-      printf("   outputs of the two forms differ in %zu of %zu elements\n", diff, a.size()); }
+      size_t diff = 0, big = 0; double worst = 0;
+      auto tof = [](unsigned short h){ unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; };
+      for (size_t i = 0; i < a.size(); ++i) if (a[i] != b[i]) { ++diff; const float fa = tof(a[i]), fb = tof(b[i]); const double rel = fabs(fa - fb) / (fabs(fa) + fabs(fb) + 1e-30);
+        worst = std::max(worst, rel); big += rel > 0.005; }      // one bf16 ulp is a relative 2^-8 .. 2^-7 of the value: rel (of the sum) <= 0.004
+      printf("   outputs of the two forms differ in %zu of %zu elements (more than one bf16 ulp apart: %zu, worst relative difference %.4f)\n", diff, a.size(), big, worst); }
 #ifdef G8_STAMP2
     for (int form = 0; form < 2; ++form) {
       CK(hipMemset(part, 0, 2048));
@@ -78,6 +91,10 @@ int main(){
           form ? "split  " : "round-2", gq, h[1]-h[0], h[2]-h[1], h[3]-h[2], h[4]-h[3], h[5]-h[4], h[6]-h[5], h[7]-h[6], h[8]-h[7], h[9]-h[8], h[10]-h[9], h[11]-h[10], h[11]-h[0]); } }
 #endif
 #ifdef G8_STAMP
+    if (c.epi==EPI8_RESID) { unsigned long long hs[64]; CK(hipMemcpy(hs, part, sizeof hs, hipMemcpyDeviceToHost));
+      for (int gq = 0; gq < 2; ++gq) { unsigned long long* e = hs + 32 + gq*16; if (!e[0]) continue; unsigned long long* h = hs + gq*16;
+        printf("   group %d LDS epilogue (cycles from the k-loop's end): sb3 sb4 issued %llu | stats cols sb0 landed %llu | sb0 + S0 done %llu | barrier + A staged %llu | sb1 ready %llu | sb2 ready %llu | sb3 ready %llu | sb4 ready %llu | sb5 ready %llu | sb6 ready %llu | sb6 done %llu | barrier + W staged %llu | sb7 ready %llu | sb7 + S7 done %llu | A / W landed %llu\n", gq,
+          e[0]-h[1], e[1]-h[1], e[2]-h[1], e[3]-h[1], e[4]-h[1], e[5]-h[1], e[6]-h[1], e[7]-h[1], e[8]-h[1], e[9]-h[1], e[10]-h[1], e[11]-h[1], e[12]-h[1], e[13]-h[1], e[14]-h[1]); } }
     { unsigned long long hs[64]; CK(hipMemcpy(hs, part, sizeof hs, hipMemcpyDeviceToHost));
       for (int gq = 0; gq < 2; ++gq) { unsigned long long* h = hs + gq*16; if (h[10]) printf("   group %d RESID epilogue: loads issued %llu | band0 wait+compute %llu | band1 load+compute %llu | stores issued %llu\n", gq, h[10]-h[1], h[11]-h[10], h[12]-h[11], h[13]-h[12]); printf("   group %d: kloop-end->aligned %llu | +2 stages & drain %llu | epilogue issue %llu | ->k0 barrier %llu | k0->k1 %llu | k1->k2 %llu | k2->k3 %llu\n", gq,
         h[0]-h[8], h[1]-h[0], h[2]-h[1], h[3]-h[2], h[4]-h[3], h[5]-h[4], h[6]-h[5]); } }
