@@ -285,6 +285,10 @@ def main():
     sync()
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
+    # the shader clock the part sustained inside the last FFN-up launch of the timed steps (boxes of one pool differ by several
+    # percent on the same binary: this is the figure to normalise fractions of a peak by); None without an encoder
+    clk_read = enc.last_clock_mhz() if enc is not None else None
+    shader_mhz, clk_seconds = clk_read if clk_read else (float("nan"), 0.0)
     scan_ms = index.profile_drain()
     plan = index.last_plan()
     enc_plan = enc.last_plan() if enc is not None else None
@@ -363,6 +367,16 @@ def main():
                                       "mfma_bf16_frac": round(enc_flops / (stack_avg * 1e-3) / 2.5e15, 4),
                                       "flops": "12 x (14,155,776 T + 4 T^2 768) + 2 x 768^2 per padded query, SURVEY 8d"},
                     "encoder_plan": enc_plan, "search": search_roof}
+        # the same fractions against the peak at the clock the part actually held (2.5 PF dense bf16 / fp16 is quoted at 2.4 GHz)
+        clk_scale = shader_mhz / 2400.0
+        roofline["sustained_shader_clock_MHz"] = round(shader_mhz, 1)
+        roofline["frac_of_clock_held_peak"] = round(tf / (PEAK_F16_MFMA_TF * clk_scale), 4)
+        roofline["encoder_stack"]["mfma_bf16_frac_of_clock_held_peak"] = round(enc_flops / (stack_avg * 1e-3) / (2.5e15 * clk_scale), 4)
+        if search_roof.get("bound") == "mfma" and search_roof.get("peak") == PEAK_F16_MFMA_TF:
+            search_roof["frac_of_clock_held_peak"] = round(search_roof["frac"] / clk_scale, 4)
+        roofline["clock_note"] = ("sustained_shader_clock_MHz = d(s_memtime) / d(s_memrealtime) x 100 MHz between the first and the last instruction of "
+                                  f"workgroup 0 of the LAST FFN-up launch of the timed steps ({clk_seconds * 1e3:.3f} ms; hac_encoder_last_clock); "
+                                  "*_of_clock_held_peak = the same achieved rate over peak x clock / 2400 MHz")
         # every kernel class of the step, from the event pairs of the TIMED steps: per-step time, share of the step, fraction of
         # the 2.5 PF bf16 / fp16 peak -- so that "dominant" can be checked from this line alone
         fl_step = {"qkv": 2.0 * T_tok * 768 * 2304 * 12, "out_proj": 2.0 * T_tok * 768 * 768 * 11, "ffn_up": 2.0 * T_tok * 768 * 3072 * 11,

@@ -1386,6 +1386,9 @@ struct hac_encoder {
     bool graph_done_armed = false;
     GrowBuf ws_gids, ws_gmask, ws_gout;
     GrowBuf ws_identgb;                   // [2][768]: gamma = 1, beta = 0
+    GrowBuf ws_clk;                       // [4] u64: hac_encoder_last_clock
+    hipStream_t clk_stream = nullptr;     // the stream of the launch that wrote it last
+    bool clk_valid = false;
 };
 
 namespace {
@@ -1643,8 +1646,15 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
             // FFN up: A = bf16(yA), the attention LayerNorm folded into W1
             g8a.A = yAb; g8a.astats = statsA; g8a.W = w.w18; g8a.N = FF; g8a.K = H; g8a.wsum = w.fold + 6 * H; g8a.cvec = w.fold + 6 * H + FF; g8a.h = h;
             g8a.n_groups = ng_up;
+            if (e->prof_mask >> 1) {   // class profiling on: this launch also reads the clock counters (hac_encoder_last_clock)
+                HAC_TRY(e->ws_clk.reserve(32));
+                g8a.clk = (unsigned long long *)e->ws_clk.p;
+                e->clk_stream = st;
+                e->clk_valid = true;
+            }
             HAC_TRY(prof_begin(e, 1 + HAC_ENC_CLASS_FFN_UP, st));
             launch8(epi_gelu, 2);
+            g8a.clk = nullptr;
             HAC_TRY(prof_end(e, 1 + HAC_ENC_CLASS_FFN_UP, st));
             g8a.n_groups = 1;
             // FFN down + residual LN1(yA) -> yF (bf16, in xb's buffer: the next layer's A operand and residual), partials
@@ -1929,7 +1939,7 @@ void hac_encoder_destroy(hac_encoder *e) {
     drop_graphs(e);
     if (e->graph_done) (void)hipEventDestroy(e->graph_done);
     for (GrowBuf *b : {&e->ws_x, &e->ws_xb, &e->ws_q, &e->ws_k, &e->ws_vt, &e->ws_ctx, &e->ws_y, &e->ws_h, &e->ws_seq, &e->ws_ids, &e->ws_mask, &e->ws_out, &e->ws_cls, &e->ws_stats, &e->ws_yb, &e->ws_part, &e->ws_idstats,
-                       &e->ws_gids, &e->ws_gmask, &e->ws_gout, &e->ws_ksplit, &e->ws_identgb})
+                       &e->ws_gids, &e->ws_gmask, &e->ws_gout, &e->ws_ksplit, &e->ws_identgb, &e->ws_clk})
         b->release();
     if (e->h_pin) (void)hipHostFree(e->h_pin);
     if (e->h_len) (void)hipHostFree(e->h_len);
@@ -2150,6 +2160,21 @@ int hac_encoder_profile_drain(hac_encoder *e, float *ms_out, int cap, int *n_out
     if (!e || !n_out || (cap > 0 && !ms_out)) return fail(HAC_ERR_INVALID, "bad arguments");
     DeviceGuard g(e->device);
     return drain_pool(e, 0, ms_out, cap, n_out);
+}
+
+int hac_encoder_last_clock(hac_encoder *e, uint64_t out[2]) {
+    if (!e || !out) return fail(HAC_ERR_INVALID, "hac_encoder_last_clock: null argument");
+    out[0] = out[1] = 0;
+    if (!e->clk_valid || !e->ws_clk.p) return HAC_OK;
+    DeviceGuard g(e->device);
+    unsigned long long h[4] = {0, 0, 0, 0};
+    HAC_HIP(hipStreamSynchronize(e->clk_stream));
+    HAC_HIP(hipMemcpy(h, e->ws_clk.p, sizeof h, hipMemcpyDeviceToHost));
+    if (h[2] > h[0] && h[3] > h[1]) {
+        out[0] = h[2] - h[0];
+        out[1] = h[3] - h[1];
+    }
+    return HAC_OK;
 }
 
 int hac_encoder_profile_drain_class(hac_encoder *e, int cls, float *ms_out, int cap, int *n_out) {

@@ -151,6 +151,15 @@ class ANCEEncoder:
         _lib.check(_lib.lib().hac_encoder_profile_drain(self._h, buf, cap, ctypes.byref(n)))
         return [float(buf[i]) for i in range(n.value)]
 
+    def last_clock_mhz(self):
+        """(shader clock in MHz, seconds) inside the most recent large-batch FFN-up launch made with class profiling on, or
+        None (hac_encoder_last_clock): what fractions of a peak are normalised by across boxes that hold different clocks."""
+        out = (ctypes.c_uint64 * 2)()
+        _lib.check(_lib.lib().hac_encoder_last_clock(self._h, out))
+        if not out[1]:
+            return None
+        return 100.0 * int(out[0]) / int(out[1]), int(out[1]) / 100e6
+
     def profile_drain_class(self, name, cap=16384):
         """Durations (ms, launch order) of the launches of one kernel class since the last drain."""
         buf = (ctypes.c_float * cap)()

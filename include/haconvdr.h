@@ -55,8 +55,9 @@ typedef enum {
 /* ------------------------------------------------------------------ errors */
 /* Message of the last failing call on this thread ("" if none).  Never NULL. */
 const char *hac_last_error(void);
-/* Library version string, e.g. "haconvdr-amd 0.4.0 (gfx950)". */
+/* Library version string, e.g. "haconvdr-amd 0.5.0 (gfx950)". */
 const char *hac_version(void);
+
 
 /* ------------------------------------------------------------------- index */
 typedef struct hac_index hac_index;
@@ -253,6 +254,13 @@ enum {
 int hac_encoder_set_profiling(hac_encoder *enc, int mask);
 int hac_encoder_profile_drain(hac_encoder *enc, float *ms_out, int cap, int *n_out);
 int hac_encoder_profile_drain_class(hac_encoder *enc, int cls, float *ms_out, int cap, int *n_out);
+/* The shader clock the part sustained inside the most recent large-batch FFN-up launch made while class profiling was on:
+ * workgroup 0 of gemm8_kernel<EPI8_GELU> reads the shader-clock counter (s_memtime) and the constant 100-MHz counter
+ * (s_memrealtime) at its first and last instruction (same CU both times: the counters of different XCDs are not aligned).
+ * out[0] = shader clocks, out[1] = 100-MHz ticks between the two readings (0, 0 if no such launch happened); waits for the
+ * stream of that launch.  clock = out[0] / out[1] x 100 MHz -- the figure fractions of a peak are normalised by, because boxes
+ * of one pool hold different clocks under the same load.  Costs the kernel nothing (two scalar reads, four stores). */
+int hac_encoder_last_clock(hac_encoder *enc, uint64_t out[2]);
 
 #ifdef __cplusplus
 }

@@ -88,3 +88,24 @@ def test_bench_four_rank_rehearsal_with_a_query_count_the_ranks_do_not_divide(tm
     np.testing.assert_array_equal(I.cpu().numpy(), g["I"])
     np.testing.assert_array_equal(D.cpu().numpy(), g["D"])
     assert len(np.unique(g["I"] // 300_000)) == 4      # every shard contributes
+
+
+def test_last_clock_reports_a_plausible_shader_clock():
+    """hac_encoder_last_clock (bench.py's sustained_shader_clock_MHz): workgroup 0 of the FFN-up kernel reads (s_memtime,
+    s_memrealtime) at its first and last instruction when class profiling is on: a shader clock inside the part's range over
+    an interval about as long as the launch's hipEvent bracket; nothing without profiling."""
+    from haconvdr_amd import synth
+    from haconvdr_amd.encoder import ANCEEncoder
+    enc = ANCEEncoder.from_state_dict(synth.ance_state_dict(0xA11CE, 2, rich=False))
+    ids, _ = synth.token_batch(3, 320, 512, fixed_len=512)
+    mask = np.ones_like(ids)
+    enc(ids, mask)
+    assert enc.last_clock_mhz() is None
+    enc.set_profiling(True, classes="all")
+    enc(ids, mask)
+    ms = enc.profile_drain_class("ffn_up")
+    mhz, seconds = enc.last_clock_mhz()
+    enc.set_profiling(False)
+    assert enc.last_plan().startswith("gemm=gemm8") and len(ms) == 1
+    assert 400.0 < mhz < 2600.0, mhz
+    assert 0.5 * ms[-1] * 1e-3 < seconds <= 1.05 * ms[-1] * 1e-3, (seconds, ms)
