@@ -18,7 +18,7 @@ search their embeddings, top-100, over the resident corpus.
           WORLD_SIZE in the environment) or plain `python bench.py --gpus N`, which starts the N ranks itself
           BEFORE anything touches a GPU (children are separate processes, nothing is re-exec'ed).
 
-Rank 0 prints ONE JSON line; DESIGN.md §4 has the roofline arithmetic.
+Rank 0 prints ONE JSON line; DESIGN.md §5 has the roofline arithmetic.
 """
 import argparse
 import json

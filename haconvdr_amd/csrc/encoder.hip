@@ -601,7 +601,7 @@ __global__ __launch_bounds__(TMT * 128, 2) void gemm_bf16_nt_kernel(GemmArgs g) 
                             // halves times rstd, the high word of the statistics pair) and v_pk_fma_f32 right behind the loads' waits, and on
                             // MI355X the LOW half of such a packed result was now and then wrong for one 16-lane pass: one element in a few
                             // thousand forwards of 6-16 k rows (found by the encoder soak in round 4; a forward repeated on the same input
-                            // differed in one sequence in ~5 % of the runs).  Not reproduced with scalar instructions.
+                            // differed in one sequence in ~5 % of the runs; LABNOTES, round 4, 2.4).  Not reproduced with scalar instructions.
                             float c0 = rs[it].x, c1 = rs[it].y, c2 = rs[it].z, c3 = rs[it].w, mean = st.x, rstd = st.y;
                             asm volatile("" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(mean), "+v"(rstd));
                             c0 = fmaf((c0 - mean) * rstd, gam.x, bet.x);

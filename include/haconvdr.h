@@ -90,7 +90,7 @@ int hac_index_add_device(hac_index *idx, const float *x_dev, int64_t n, void *hi
  * With many (query, row) pairs (>= 48 queries, >= 1e8 pairs, k <= 192, d % 64 == 0, d >= 192) the
  * rows are first screened on the fp16 matrix pipe under a proven error bound, the few
  * candidates are rescored exactly and each query's list is certified complete; queries
- * that cannot be certified are searched again by the exact fp32 kernels.
+ * that cannot be certified are searched again by the exact fp32 kernels ("Prefilter with a certificate").
  * The results are the same bits either way.  hac_index_set_option(idx, "split", "0") disables
  * the screen, "1" applies it whenever the shape allows (tests), "auto" decides by size.
  * The host entry point reads the certificates back (and may retry many failures with three

@@ -1,4 +1,4 @@
-// Probe for the attention kernel's softmax (DESIGN 2.3 / VERDICT r3 item 5a): what does one 2^x cost on the VALU of a SIMD
+// Probe for the attention kernel's softmax (LABNOTES rounds 1-4, 2.3 / VERDICT r3 item 5a): what does one 2^x cost on the VALU of a SIMD
 //   A  v_exp_f32 (the shipped path: one transcendental instruction per element)
 //   B  packed fp16: clamp, round-to-integer by the 1.5 * 2^10 magic add, f = x - n, cubic 2^f, scale 2^n built by a 16-bit shift/add, multiply
 //      (two elements per instruction; P is rounded to bf16 behind it anyway)

@@ -1,4 +1,4 @@
-// Probe: the packed-fp32 sequence that went wrong in the 128-row GEMM family's residual epilogue ("A wrong bit the soak
+// Probe: the packed-fp32 sequence that went wrong in the 128-row GEMM family's residual epilogue (LABNOTES rounds 1-4, 2.4, "A wrong bit the soak
 // found"), in isolation.  Every lane loads four residual floats, a (mean, rstd) pair and gamma / beta vectors from large buffers (so
 // that the loads miss and return at uneven times), evaluates  (r - mean) * rstd * gamma + beta  as the vector expression hipcc turned
 // into v_sub_f32 x 4, v_pk_mul_f32 ... op_sel:[0,1], v_pk_fma_f32, and again component by component with every value pinned to its

@@ -1,5 +1,5 @@
 """Development: is a forward bit-reproducible?  One handle runs every random batch TWICE; any difference is a defect (round 4 found
-one this way: DESIGN.md 2.4, "A wrong bit the soak found").
+one this way: LABNOTES rounds 1-4, 2.4, "A wrong bit the soak found").
   python tools/repeat_encoder.py SECONDS LAYERS B[,B...] L[,L...] [option=value ...]     e.g.  20 2 130,100 64,16 gemm=auto"""
 import os, sys, time, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
