@@ -212,6 +212,15 @@ __global__ __launch_bounds__(256) void tile_rows_kernel(const float4 *__restrict
 // The fp16 image of groups [g0, g0 + gridDim.x) of a segment from its fp32 tiles: what tile_rows_kernel writes beside the
 // tiles once the image exists.  It is built lazily, by the first search that takes the prefilter path: an index that only
 // ever sees a few queries per call (the HBM-bound regime) or has split = "0" never pays the +50 % of HBM.
+// T64 tiles of groups g0 + blockIdx.x -> the same rows row-major ([row][K4] float4): the rescoring's copy (see ensure_row_image)
+__global__ __launch_bounds__(256) void untile_rows_kernel(const float4 *__restrict__ seg, float4 *__restrict__ rows, long g0, int K4) {
+    const long g = g0 + blockIdx.x;
+    const int r = threadIdx.x & 63, tq = threadIdx.x >> 6;
+    const float4 *src = seg + (size_t)g * K4 * GROUP_ROWS + r;
+    float4 *dst = rows + ((size_t)g * GROUP_ROWS + r) * K4;
+    for (int t = tq; t < K4; t += 4) dst[t] = src[(size_t)t * GROUP_ROWS];
+}
+
 __global__ __launch_bounds__(256) void half_image_kernel(const float4 *__restrict__ seg, uint4 *__restrict__ hseg, long g0, int K4) {
     const long gd = g0 + blockIdx.x;
     const gf4ptr_t src = reinterpret_cast<gf4ptr_t>(seg) + gd * (long)K4 * GROUP_ROWS;
@@ -950,6 +959,8 @@ struct Segment {
     int64_t cap_rows = 0;    // multiple of 64
     int64_t rows = 0;
     int64_t h_rows = 0;      // rows whose fp16 image is current (tile_rows_kernel keeps it current once hbuf exists)
+    float4 *rbuf = nullptr;  // cap_rows * d fp32, row-major: the rescoring's copy (small indexes only, best effort: ensure_row_image)
+    int64_t r_rows = 0;      // rows of it that are current
 };
 
 struct DeviceIndex {
@@ -960,6 +971,7 @@ struct DeviceIndex {
     std::vector<Segment> segs;
     int64_t ntotal = 0;
     SegDesc *d_segs = nullptr;
+    const float4 **d_rimg = nullptr, **h_rimg = nullptr;   // per live segment: its row-major copy for the rescoring, or null (ensure_row_image)
     bool segs_dirty = true;
     // Tuning / test switches.  The HAC_* environment variables are read ONCE, when the index is created, as the
     // defaults; hac_index_set_option() changes them on a live handle (tests, bench).
@@ -972,6 +984,7 @@ struct DeviceIndex {
         bool no_p8 = false;
         int seed_groups_max = 0;         // cap of the seeding pass of the prefilter scan, in 64-row groups; 0 = 14 sqrt(groups)
         int split_decide = -1;           // who reads the certificates: -1 by entry point (host API: host, *_device: device), 0 host, 1 device
+        int rescore_rows = -1;           // row-major copy for the rescoring: -1 by size (<= RESCORE_ROWS_MAX rows), 0 never, 1 whenever it can be allocated
         int debug_max_pass = 0;          // tests: pass bound of the candidate loops (0 = the kernels' own, which no legal input reaches)
         int scan_passes = 0;             // prefilter scan: 0 by size, 1..5 pins the number of passes (threshold refreshes between them)
         int pass_cut[2] = {0, 0};        // where the passes end, in thousandths of the row groups (option "scan_pass_cuts" = "a,b"); 0 = by size
@@ -1056,6 +1069,9 @@ struct DeviceIndex {
         } else if (n == "scan_passes") {
             if (!one_of({"auto", "1", "2", "3", "4", "5"})) return HAC_ERR_INVALID;
             tune.scan_passes = v == "auto" ? 0 : atoi(v.c_str());
+        } else if (n == "rescore_rows") {
+            if (!one_of({"0", "1", "auto"})) return HAC_ERR_INVALID;
+            tune.rescore_rows = v == "0" ? 0 : (v == "1" ? 1 : -1);
         } else if (n == "debug_max_pass") {
             char *end = nullptr;
             const long t = strtol(v.c_str(), &end, 10);
@@ -1120,6 +1136,9 @@ struct DeviceIndex {
         HAC_HIP(hipEventCreateWithFlags(&ev_tail, hipEventDisableTiming));
         HAC_HIP(hipMalloc((void **)&d_segs, sizeof(SegDesc) * MAX_SEG));
         HAC_HIP(hipHostMalloc((void **)&h_segs, sizeof(SegDesc) * MAX_SEG, hipHostMallocDefault));
+        HAC_HIP(hipMalloc((void **)&d_rimg, sizeof(float4 *) * MAX_SEG));
+        HAC_HIP(hipMemset(d_rimg, 0, sizeof(float4 *) * MAX_SEG));
+        HAC_HIP(hipHostMalloc((void **)&h_rimg, sizeof(float4 *) * MAX_SEG, hipHostMallocDefault));
         for (int i = 0; i < 2; ++i) HAC_HIP(hipEventCreateWithFlags(&stage_ev[i], hipEventDisableTiming));
         HAC_TRY(ws_norm.reserve(16));
         HAC_HIP(hipMemsetAsync(ws_norm.p, 0, 16, stream));
@@ -1156,10 +1175,13 @@ struct DeviceIndex {
         for (auto &s : segs) {
             if (s.buf) (void)hipFree(s.buf);
             if (s.hbuf) (void)hipFree(s.hbuf);
+            if (s.rbuf) (void)hipFree(s.rbuf);
         }
         segs.clear();
         if (d_segs) (void)hipFree(d_segs);
         if (h_segs) (void)hipHostFree(h_segs);
+        if (d_rimg) (void)hipFree(d_rimg);
+        if (h_rimg) (void)hipHostFree(h_rimg);
         if (h_pin) (void)hipHostFree(h_pin);
         for (GrowBuf *b : {&ws_partial, &ws_pcnt, &ws_seedkeys, &ws_thr, &ws_thrglob, &ws_q, &ws_qt, &ws_keys, &ws_D, &ws_I, &ws_stage[0],
                            &ws_stage[1], &ws_err, &ws_norm, &ws_qsplit, &ws_delta, &ws_cand, &ws_akeys, &ws_fail, &ws_stat, &ws_fbidx[0], &ws_fbidx[1],
@@ -1201,16 +1223,19 @@ struct DeviceIndex {
                 Segment s = segs[i];
                 s.rows = 0;
                 s.h_rows = 0;
+                s.r_rows = 0;
                 keep.push_back(s);
             } else if (segs[i].buf) {
                 HAC_HIP(hipFree(segs[i].buf));
                 if (segs[i].hbuf) HAC_HIP(hipFree(segs[i].hbuf));
+                if (segs[i].rbuf) HAC_HIP(hipFree(segs[i].rbuf));
             }
         }
         segs.swap(keep);
         ntotal = 0;
         segs_dirty = true;
         half_image_unavailable = false;
+        row_image_unavailable = false;
         HAC_HIP(hipMemsetAsync(ws_norm.p, 0, 16, stream));
         HAC_HIP(hipMemsetAsync(ws_err.p, 0, 16, stream));
         HAC_HIP(hipStreamSynchronize(stream));
@@ -1299,6 +1324,54 @@ struct DeviceIndex {
         return HAC_OK;
     }
 
+    // The rescoring reads ~130 candidate rows per query, each a different row: out of the T64 tiles that is one useful 16-byte
+    // piece per 64-byte sector (0.43-0.49 ms per 1000 queries whatever the corpus size: 1.6 GB fetched for 0.4 GB used) -- the
+    // price of the layout that lets scan16_kernel stream at 0.77 of the HBM rate.  On a small index that is a fifth of a
+    // search (1M rows: 2.15 ms), on 25M rows 1.5 %.  So small indexes keep the rows once more, ROW-MAJOR, for the rescoring
+    // alone (whole 128-byte lines per candidate): built lazily from the tiles by the first prefilter search, like the fp16
+    // image, +100 % of a corpus that is small by definition, best effort (an allocation that fails just leaves the tiles'
+    // route), kept current by later searches, dropped by consolidate.  Same fmaf chain over the same values: same bits.
+    static constexpr int64_t RESCORE_ROWS_MAX = 12000000;
+    bool row_image_unavailable = false;
+    const char *rescore_from() const {   // what the plan text says: "rows" when every live segment has a current row-major copy
+        bool all = !segs.empty();
+        for (auto &sg : segs)
+            if (sg.rows > 0 && !(sg.rbuf && sg.r_rows == sg.rows)) all = false;
+        return all ? "rows" : "tiles";
+    }
+    int ensure_row_image(hipStream_t st) {
+        const bool want = tune.rescore_rows == 1 || (tune.rescore_rows < 0 && ntotal <= RESCORE_ROWS_MAX);
+        if (!want || row_image_unavailable) {
+            bool any = false;
+            for (auto &s : segs) any |= s.rbuf != nullptr && s.r_rows > 0;
+            if (any && !want) {            // switched off on a live handle: the descriptors must stop pointing at it
+                for (auto &s : segs) s.r_rows = 0;
+                segs_dirty = true;
+            }
+            return HAC_OK;
+        }
+        for (auto &s : segs) {
+            if (s.rows == 0 || (s.rbuf && s.r_rows == s.rows)) continue;
+            if (!s.rbuf) {
+                if (hipMalloc((void **)&s.rbuf, (size_t)s.cap_rows * d * 4) != hipSuccess) {
+                    s.rbuf = nullptr;
+                    (void)hipGetLastError();
+                    row_image_unavailable = true;      // until the next add / reset: nothing is retried per search
+                    return HAC_OK;
+                }
+                s.r_rows = 0;
+            }
+            const long g_lo = (long)(s.r_rows / GROUP_ROWS), g_hi = (long)((s.rows + GROUP_ROWS - 1) / GROUP_ROWS);
+            if (g_hi > g_lo) {
+                untile_rows_kernel<<<dim3((unsigned)(g_hi - g_lo)), dim3(256), 0, st>>>(s.buf, s.rbuf, g_lo, K4);
+                HAC_HIP(hipGetLastError());
+            }
+            s.r_rows = s.rows;
+            segs_dirty = true;
+        }
+        return HAC_OK;
+    }
+
     // fuse all segments into one allocation (groups are self-contained, so this is plain copies)
     int consolidate(hipStream_t st) {
         int64_t total_cap = 0;
@@ -1318,6 +1391,7 @@ struct DeviceIndex {
         for (auto &s : segs) {
             HAC_HIP(hipFree(s.buf));
             if (s.hbuf) HAC_HIP(hipFree(s.hbuf));
+            if (s.rbuf) HAC_HIP(hipFree(s.rbuf));
         }
         segs.clear();
         segs.push_back(big);
@@ -1351,6 +1425,7 @@ struct DeviceIndex {
         ntotal += n;
         segs_dirty = true;
         half_image_unavailable = false;   // (memory may have been freed since: the next eligible search tries again)
+        row_image_unavailable = false;
         return HAC_OK;
     }
 
@@ -1411,12 +1486,14 @@ struct DeviceIndex {
             if (s.rows == 0) continue;
             h[n].ptr = s.buf;
             h[n].himg = s.hbuf;
+            h_rimg[n] = (s.rbuf && s.r_rows == s.rows) ? s.rbuf : nullptr;   // (a table of its own: SegDesc is cached in the scan kernels' LDS, which is full)
             h[n].gstart = g;
             h[n].pad_ = 0;
             g += (u32)((s.rows + GROUP_ROWS - 1) / GROUP_ROWS);
             ++n;
         }
         if (n) HAC_HIP(hipMemcpyAsync(d_segs, h, sizeof(SegDesc) * n, hipMemcpyHostToDevice, st));
+        if (n) HAC_HIP(hipMemcpyAsync(d_rimg, h_rimg, sizeof(float4 *) * n, hipMemcpyHostToDevice, st));
         nseg_live = n;
         segs_dirty = false;
         return HAC_OK;
@@ -1719,6 +1796,7 @@ struct DeviceIndex {
         const int terms = level == 0 ? tune.split_terms : 3;   // split_terms = 3: tests pin the first level
         plan_collect(false);                                   // an earlier device-decided search nobody asked about
         HAC_TRY(ensure_half_image(st));
+        HAC_TRY(ensure_row_image(st));
         HAC_TRY(upload_segs(st));
         const u32 G = (u32)((ntotal + GROUP_ROWS - 1) / GROUP_ROWS);
         const int64_t chunk = std::min<int64_t>(nq, SPLIT_CHUNK);
@@ -1852,7 +1930,7 @@ struct DeviceIndex {
             // the corpus; everything the next chunk's scan reuses is already consumed)
             HAC_HIP(hipEventRecord(ev_chunk[n_chunks & 1], st));
             HAC_HIP(hipStreamWaitEvent(stream2, ev_chunk[n_chunks & 1], 0));
-            rescore_kernel<<<dim3((unsigned)n), dim3(256), 0, stream2>>>(a, akeys_c, delta_c, K2, k, keys_out + (size_t)off * k,
+            rescore_kernel<<<dim3((unsigned)n), dim3(256), 0, stream2>>>(a, d_rimg, akeys_c, delta_c, K2, k, keys_out + (size_t)off * k,
                                                                         (u32 *)ws_fail.p + off, (u32 *)ws_stat.p);
             HAC_HIP(hipGetLastError());
             P_last = P;
@@ -1891,8 +1969,8 @@ struct DeviceIndex {
                                                                                                   (int)nq, k, keys_out, nf_dev);
             HAC_HIP(hipGetLastError());
             ++split_searches;
-            snprintf(plan_head, sizeof plan_head, "split: scanh_kernel<%d> grid=(%ld,%d) NQ=%d K2=%d chunks=%d lds=%zu seed=%d passes=%d", terms, P_last,
-                     n_qtiles_last, SH_NQ, K2, n_chunks, lds, seeded, passes_last);
+            snprintf(plan_head, sizeof plan_head, "split: scanh_kernel<%d> grid=(%ld,%d) NQ=%d K2=%d chunks=%d lds=%zu seed=%d passes=%d rescore=%s", terms, P_last,
+                     n_qtiles_last, SH_NQ, K2, n_chunks, lds, seeded, passes_last, rescore_from());
             snprintf(last_plan, sizeof last_plan, "%s fallback=device-side/%lld", plan_head, (long long)nq);
             const int slot = plan_slot();
             HAC_HIP(hipMemcpyAsync(h_plan + 2 * slot, ws_stat.p, 8, hipMemcpyDeviceToHost, st));
@@ -1909,8 +1987,8 @@ struct DeviceIndex {
         std::memcpy(&maxratio, &h_fb[1], 4);
         if (level == 0) ++split_searches;
         char plan_here[sizeof last_plan];
-        snprintf(plan_here, sizeof plan_here, "split: scanh_kernel<%d> grid=(%ld,%d) NQ=%d K2=%d chunks=%d lds=%zu seed=%d passes=%d fallback=%u/%lld err/bound=%.3g",
-                 terms, P_last, n_qtiles_last, SH_NQ, K2, n_chunks, lds, seeded, passes_last, nfail, (long long)nq, (double)maxratio);
+        snprintf(plan_here, sizeof plan_here, "split: scanh_kernel<%d> grid=(%ld,%d) NQ=%d K2=%d chunks=%d lds=%zu seed=%d passes=%d rescore=%s fallback=%u/%lld err/bound=%.3g",
+                 terms, P_last, n_qtiles_last, SH_NQ, K2, n_chunks, lds, seeded, passes_last, rescore_from(), nfail, (long long)nq, (double)maxratio);
         std::memcpy(last_plan, plan_here, sizeof last_plan);
         plan_text_slot = -1;
         if (nfail == 0) return HAC_OK;

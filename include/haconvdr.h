@@ -141,7 +141,11 @@ int hac_index_last_status(hac_index *idx);
  * "scan_passes" = "auto" | "1" .. "5" (prefilter: passes of the main scan, the thresholds refreshed from everything found so
  * far between them; auto: 3 from 1.6M rows, 4 from 8.4M), "scan_pass_cuts" = "auto" | "a,b" (where the first two passes end, in
  * thousandths of the rows; auto: the first after ~6k 64-row groups, the others in geometric progression towards the corpus), "debug_max_pass" = integer >= 0 (tests: the pass bound of the
- * candidate loops; 0 = the bound no legal input reaches).
+ * candidate loops; 0 = the bound no legal input reaches),
+ * "rescore_rows" = "auto" | "0" | "1": the prefilter's exact rescoring reads ~130 scattered rows per query; out of the T64 tiles
+ * that is one useful 16-byte piece per 64-byte sector.  Small indexes (auto: <= 12M rows) therefore keep their rows once more,
+ * row-major, for the rescoring alone (+100 % of a small corpus, built lazily by the first prefilter search, best effort: when the
+ * allocation fails the tiles are read as before); "1" builds it at any size, "0" never.  Same bits either way.
  * Any other name or value is HAC_ERR_INVALID (never a silent default).
  * The HAC_<NAME> environment variables give the defaults and are read once, in hac_index_create. */
 int hac_index_set_option(hac_index *idx, const char *name, const char *value);

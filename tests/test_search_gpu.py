@@ -966,6 +966,55 @@ def test_half_precision_image_is_built_lazily(oracle):
     assert_same(D, I, D0, I0)
 
 
+def test_row_major_copy_for_the_rescoring_is_lazy_optional_and_changes_no_bit(oracle):
+    """Round 5: small indexes keep their rows once more, row-major, so that the prefilter's exact rescoring reads whole lines
+    instead of one 16-byte piece per sector of the T64 tiles (option "rescore_rows" = auto | 0 | 1).  The copy appears with the
+    first prefilter search (never with the exact kernels), follows later adds (into the tail group, into a new segment), can be
+    switched off on a live handle, and the results are the same bits with and without it -- and the oracle's."""
+    import torch
+    from haconvdr_amd.index import FlatIPIndex
+    x, q, _ = cases.search_case_inputs("gauss", 0x7B5, 260000, 96)
+    corpus = 200000 * 768 * 4
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free0 = torch.cuda.mem_get_info()[0]
+    idx = FlatIPIndex(768)
+    idx.add(x[:200000])
+    idx.set_option("rescore_rows", "0")
+    idx.set_option("split", "1")
+    D0, I0 = idx.search(q, 100)
+    assert "rescore=tiles" in idx.last_plan(), idx.last_plan()
+    torch.cuda.synchronize()
+    used_tiles = free0 - torch.cuda.mem_get_info()[0]
+    idx.set_option("rescore_rows", "auto")
+    D1, I1 = idx.search(q, 100)
+    assert "rescore=rows" in idx.last_plan(), idx.last_plan()
+    torch.cuda.synchronize()
+    used_rows = free0 - torch.cuda.mem_get_info()[0]
+    assert used_rows > used_tiles + 0.9 * corpus, (used_rows, used_tiles)          # one more copy of the rows, now
+    assert_same(D1, I1, D0, I0)
+    assert_same(D1, I1, *oracle.flat_ip_search(x[:200000], q, 100))
+    idx.add(x[200000:200037])                                      # into the tail group of a segment that owns a copy
+    idx.add(x[200037:])                                            # ... and a new segment
+    D2, I2 = idx.search(q, 100)
+    assert "rescore=rows" in idx.last_plan(), idx.last_plan()
+    idx.set_option("rescore_rows", "0")
+    D3, I3 = idx.search(q, 100)
+    assert "rescore=tiles" in idx.last_plan(), idx.last_plan()
+    assert_same(D2, I2, D3, I3)
+    sel = np.arange(0, 96, 6)
+    assert_same(D2[sel], I2[sel], *oracle.flat_ip_search(x, q[sel], 100))
+    idx.set_option("rescore_rows", "1")
+    idx.reset()
+    idx.add(x[:70001])
+    D4, I4 = idx.search(q, 100)
+    assert "rescore=rows" in idx.last_plan(), idx.last_plan()
+    assert_same(D4[sel], I4[sel], *oracle.flat_ip_search(x[:70001], q[sel], 100))
+    from haconvdr_amd._lib import HacError
+    with pytest.raises(HacError):
+        idx.set_option("rescore_rows", "2")
+
+
 @pytest.mark.gpu
 def test_device_decided_fallback_ignores_stale_rows_behind_the_count(oracle):
     """The device-decided fallback gathers the failed queries into a buffer sized for all nq and searches whole 32-query
