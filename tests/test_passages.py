@@ -68,6 +68,67 @@ def test_encode_passages_vs_reference_blocks(tmp_path):
     np.testing.assert_array_equal(np.concatenate([b[0] for b in blocks]), e)
 
 
+G61 = os.path.join(os.path.dirname(__file__), "golden", "passages61")
+
+
+def test_multi_block_fixture_is_what_the_reference_writes():
+    """tests/golden/passages61/ (make_golden_passages_multiblock.py: the reference's writer loop with its 2 500 000-per-block
+    literal replaced by 20): 61 records at batch 4 -> three blocks of 20 and the tail flush of 1, ids = the enumerate index."""
+    from haconvdr_amd.passages import TokenizedPassages, read_embedding_block
+    from tests.golden.make_golden_passages_multiblock import inputs
+    tp = TokenizedPassages(os.path.join(G61, "passages"))
+    ids, lens = inputs()
+    got_ids, got_lens = tp.batch(0, 61)
+    np.testing.assert_array_equal(got_ids, ids)
+    np.testing.assert_array_equal(got_lens, lens)
+    sizes, all_ids = [], []
+    for b in range(4):
+        e, i = read_embedding_block(G61, b, mmap=True)
+        assert e.dtype == np.float32 and e.shape[1] == 768 and i.dtype == np.int64 and len(i) == len(e)
+        sizes.append(len(e))
+        all_ids.append(i)
+    assert sizes == [20, 20, 20, 1] and not os.path.exists(os.path.join(G61, "passage_emb_block_4.pb"))
+    np.testing.assert_array_equal(np.concatenate(all_ids), np.arange(61))
+
+
+@pytest.mark.gpu
+def test_encode_passages_writes_the_references_blocks_across_block_boundaries(tmp_path):
+    """The block rule (gen_doc_embeddings.py:87-88), the writer at a boundary (:127-142) and the tail flush (:144-155) against
+    what the REFERENCE's loop wrote: same files, same shapes, same ids, embeddings inside the fixture-scaled bounds (content-
+    sensitive weights: different passages are far apart, and the same embeddings shifted by one passage must fail); one rank
+    and two ranks (block b belongs to rank b % 2) give the same files."""
+    from haconvdr_amd import synth
+    from haconvdr_amd.encoder import ANCEEncoder
+    from haconvdr_amd.passages import TokenizedPassages, encode_passages, read_embedding_block
+    from tests import parity
+    from tests.golden import make_golden_passages_multiblock as mk
+    enc = ANCEEncoder.from_state_dict(synth.ance_state_dict(0xA11CE, mk.LAYERS, layer_matrix_std=mk.STD))
+    tp = TokenizedPassages(os.path.join(G61, "passages"))
+    n = encode_passages(enc, tp, str(tmp_path / "one"), per_gpu_eval_batch_size=mk.BATCH, n_gpu=1, expect_per_block_passage_num=mk.PER_BLOCK)
+    assert n == 61
+    assert sorted(os.listdir(tmp_path / "one")) == sorted(f for f in os.listdir(G61) if f.startswith("passage_emb"))
+    got, ref = [], []
+    for b in range(4):
+        e, i = read_embedding_block(str(tmp_path / "one"), b)
+        re_, ri = read_embedding_block(G61, b)
+        assert e.shape == re_.shape and e.dtype == np.float32 and i.dtype == np.int64
+        np.testing.assert_array_equal(i, ri)
+        got.append(e)
+        ref.append(np.asarray(re_))
+    got, ref = np.concatenate(got), np.concatenate(ref)
+    m = parity.assert_embeddings_match(got, ref, what="passages61")
+    parity.assert_negative_control(got, ref)
+    assert m["spread"]["raw_min"] > 0.01, m["spread"]
+    for r in range(2):
+        encode_passages(enc, tp, str(tmp_path / "two"), per_gpu_eval_batch_size=mk.BATCH, n_gpu=1, rank=r, world_size=2,
+                        expect_per_block_passage_num=mk.PER_BLOCK)
+    for b in range(4):
+        e2, i2 = read_embedding_block(str(tmp_path / "two"), b)
+        e1, i1 = read_embedding_block(str(tmp_path / "one"), b)
+        np.testing.assert_array_equal(i2, i1)
+        np.testing.assert_array_equal(e2, e1)
+
+
 @pytest.mark.gpu
 def test_encode_then_search_end_to_end(tmp_path):
     """Blocks written by encode_passages are searchable by search_one_by_one: a passage's own
