@@ -29,7 +29,7 @@ int main(int argc, char** argv){
   SeqInfo s{}; CK(hipMalloc(&s.lens,B*4)); CK(hipMalloc(&s.len32,B*4)); CK(hipMalloc(&s.off,(B+1)*4)); CK(hipMalloc(&s.order,B*4)); CK(hipMalloc(&s.ncls,8));
   CK(hipMemcpy(s.lens,lens.data(),B*4,hipMemcpyHostToDevice)); CK(hipMemcpy(s.len32,len32.data(),B*4,hipMemcpyHostToDevice)); CK(hipMemcpy(s.off,off.data(),(B+1)*4,hipMemcpyHostToDevice));
   CK(hipMemcpy(s.order,order.data(),B*4,hipMemcpyHostToDevice)); CK(hipMemcpy(s.ncls,ncls.data(),8,hipMemcpyHostToDevice));
-  AttnArgs a{}; a.q=q; a.k=k; a.v16=vt; a.ctx=ctx; a.s=s; a.cls_only=0;
+  AttnArgs a{}; a.q=q; a.k=k; a.v16=vt; a.ctx=ctx; a.s=s; a.cls_only=0; a.qsplit=1; a.one_class=0;
   CK(hipFuncSetAttribute((const void *)attention_stream_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920));
   CK(hipFuncSetAttribute((const void *)attention_stream_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
   auto launch=[&]{ if (L > 256) attention_stream_kernel<16><<<256,1024,163840>>>(a); else attention_stream_kernel<8><<<512,512,81920>>>(a); };
