@@ -1236,6 +1236,7 @@ struct DeviceIndex {
         segs_dirty = true;
         half_image_unavailable = false;
         row_image_unavailable = false;
+        split_searches_since_add = 0;
         HAC_HIP(hipMemsetAsync(ws_norm.p, 0, 16, stream));
         HAC_HIP(hipMemsetAsync(ws_err.p, 0, 16, stream));
         HAC_HIP(hipStreamSynchronize(stream));
@@ -1332,6 +1333,11 @@ struct DeviceIndex {
     // image, +100 % of a corpus that is small by definition, best effort (an allocation that fails just leaves the tiles'
     // route), kept current by later searches, dropped by consolidate.  Same fmaf chain over the same values: same bits.
     static constexpr int64_t RESCORE_ROWS_MAX = 12000000;
+    // auto mode builds the copy with the THIRD prefilter search after the last add / reset: making it moves twice the corpus
+    // bytes (1M rows: ~2 ms, the saving of about seven searches), so an index that is searched once per block -- the reference's
+    // add / search / reset loop (:98-122) -- never pays for it (measured: 5 -> 12-15 ms per 2.5M-row block when it did)
+    static constexpr int RESCORE_ROWS_AFTER = 2;
+    int split_searches_since_add = 0;
     bool row_image_unavailable = false;
     const char *rescore_from() const {   // what the plan text says: "rows" when every live segment has a current row-major copy
         bool all = !segs.empty();
@@ -1340,7 +1346,8 @@ struct DeviceIndex {
         return all ? "rows" : "tiles";
     }
     int ensure_row_image(hipStream_t st) {
-        const bool want = tune.rescore_rows == 1 || (tune.rescore_rows < 0 && ntotal <= RESCORE_ROWS_MAX);
+        const bool want = tune.rescore_rows == 1 ||
+                          (tune.rescore_rows < 0 && ntotal <= RESCORE_ROWS_MAX && split_searches_since_add++ >= RESCORE_ROWS_AFTER);
         if (!want || row_image_unavailable) {
             bool any = false;
             for (auto &s : segs) any |= s.rbuf != nullptr && s.r_rows > 0;
@@ -1426,6 +1433,7 @@ struct DeviceIndex {
         segs_dirty = true;
         half_image_unavailable = false;   // (memory may have been freed since: the next eligible search tries again)
         row_image_unavailable = false;
+        split_searches_since_add = 0;
         return HAC_OK;
     }
 
