@@ -41,6 +41,7 @@ while time.time() - t0 < budget:
     passes = str(rng.choice(["auto", "2", "3", "4", "5"]))
     cuts = str(rng.choice(["auto", "100,400", "50,120", "300,600"]))
     seed_groups = str(rng.choice(["0", "768", "4096"]))
+    rescore_rows = str(rng.choice(["auto", "0", "1", "1"]))   # round 5: the rescoring's row-major copy (auto: from the third search of an index on)
     for split in ("1", "0"):
         idx = FlatIPIndex(768)
         idx.set_option("split", split)
@@ -48,6 +49,7 @@ while time.time() - t0 < budget:
             idx.set_option("scan_passes", passes)
             idx.set_option("scan_pass_cuts", cuts)
             idx.set_option("seed_groups_max", seed_groups)
+            idx.set_option("rescore_rows", rescore_rows)
         for i in range(0, n, 250_000):
             idx.add_tensor(x[i:i + 250_000])
         idxs[split] = idx
@@ -64,7 +66,7 @@ while time.time() - t0 < budget:
         ok = ok and same
         if not same:
             bad = (res[0][1] != res[1][1]).nonzero()
-            print("MISMATCH", n, qr.shape[0], k, kind, passes, cuts, seed_groups, bad[:5].tolist(), res[0][2], flush=True)
+            print("MISMATCH", n, qr.shape[0], k, kind, passes, cuts, seed_groups, rescore_rows, bad[:5].tolist(), res[0][2], flush=True)
             sys.exit(1)
     del idxs
     n_cases += 1
