@@ -1387,7 +1387,6 @@ struct hac_encoder {
     GrowBuf ws_gids, ws_gmask, ws_gout;
     GrowBuf ws_identgb;                   // [2][768]: gamma = 1, beta = 0
     GrowBuf ws_clk;                       // [4] u64: hac_encoder_last_clock
-    hipStream_t clk_stream = nullptr;     // the stream of the launch that wrote it last
     bool clk_valid = false;
 };
 
@@ -1649,7 +1648,6 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
             if (e->prof_mask >> 1) {   // class profiling on: this launch also reads the clock counters (hac_encoder_last_clock)
                 HAC_TRY(e->ws_clk.reserve(32));
                 g8a.clk = (unsigned long long *)e->ws_clk.p;
-                e->clk_stream = st;
                 e->clk_valid = true;
             }
             HAC_TRY(prof_begin(e, 1 + HAC_ENC_CLASS_FFN_UP, st));
@@ -2168,7 +2166,7 @@ int hac_encoder_last_clock(hac_encoder *e, uint64_t out[2]) {
     if (!e->clk_valid || !e->ws_clk.p) return HAC_OK;
     DeviceGuard g(e->device);
     unsigned long long h[4] = {0, 0, 0, 0};
-    HAC_HIP(hipStreamSynchronize(e->clk_stream));
+    HAC_HIP(hipDeviceSynchronize());   // (not the stream of that launch: the caller may have destroyed it since)
     HAC_HIP(hipMemcpy(h, e->ws_clk.p, sizeof h, hipMemcpyDeviceToHost));
     if (h[2] > h[0] && h[3] > h[1]) {
         out[0] = h[2] - h[0];

@@ -1346,16 +1346,24 @@ struct DeviceIndex {
         return all ? "rows" : "tiles";
     }
     int ensure_row_image(hipStream_t st) {
-        const bool want = tune.rescore_rows == 1 ||
-                          (tune.rescore_rows < 0 && ntotal <= RESCORE_ROWS_MAX && split_searches_since_add++ >= RESCORE_ROWS_AFTER);
-        if (!want || row_image_unavailable) {
-            bool any = false;
-            for (auto &s : segs) any |= s.rbuf != nullptr && s.r_rows > 0;
-            if (any && !want) {            // switched off on a live handle: the descriptors must stop pointing at it
-                for (auto &s : segs) s.r_rows = 0;
+        const bool allowed = tune.rescore_rows == 1 || (tune.rescore_rows < 0 && ntotal <= RESCORE_ROWS_MAX);
+        if (!allowed) {   // switched off on a live handle, or grown past the size that gets one: the copies go (hipFree waits for their readers)
+            for (auto &s : segs) {
+                if (!s.rbuf) continue;
+                HAC_HIP(hipFree(s.rbuf));
+                s.rbuf = nullptr;
+                s.r_rows = 0;
                 segs_dirty = true;
             }
             return HAC_OK;
+        }
+        if (row_image_unavailable) return HAC_OK;
+        if (tune.rescore_rows < 0) {
+            // an index that HAS a copy keeps it current (an add then costs the new rows once more, on the device); one that has
+            // none waits for its third search
+            bool have = false;
+            for (auto &s : segs) have |= s.rbuf != nullptr && s.r_rows > 0;
+            if (!have && split_searches_since_add++ < RESCORE_ROWS_AFTER) return HAC_OK;
         }
         for (auto &s : segs) {
             if (s.rows == 0 || (s.rbuf && s.r_rows == s.rows)) continue;

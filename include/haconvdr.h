@@ -145,8 +145,9 @@ int hac_index_last_status(hac_index *idx);
  * "rescore_rows" = "auto" | "0" | "1": the prefilter's exact rescoring reads ~130 scattered rows per query; out of the T64 tiles
  * that is one useful 16-byte piece per 64-byte sector.  Small indexes (auto: <= 12M rows) therefore keep their rows once more,
  * row-major, for the rescoring alone (+100 % of a small corpus, built lazily by the THIRD prefilter search after the last add /
- * reset -- an index searched once per block, the reference's add / search / reset loop, never pays for it --, best effort: when the
- * allocation fails the tiles are read as before); "1" builds it with the first such search at any size, "0" never.  Same bits either way.
+ * reset of an index that has none -- an index searched once per block, the reference's add / search / reset loop, never pays for
+ * it --, kept current across later adds, best effort: when the allocation fails the tiles are read as before); "1" builds it with the
+ * first such search at any size, "0" never (and frees one that exists, as does growing past the size).  Same bits either way.
  * Any other name or value is HAC_ERR_INVALID (never a silent default).
  * The HAC_<NAME> environment variables give the defaults and are read once, in hac_index_create. */
 int hac_index_set_option(hac_index *idx, const char *name, const char *value);

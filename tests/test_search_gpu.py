@@ -969,9 +969,9 @@ def test_half_precision_image_is_built_lazily(oracle):
 def test_row_major_copy_for_the_rescoring_is_lazy_optional_and_changes_no_bit(oracle):
     """Round 5: small indexes keep their rows once more, row-major, so that the prefilter's exact rescoring reads whole lines
     instead of one 16-byte piece per sector of the T64 tiles (option "rescore_rows" = auto | 0 | 1).  The copy appears with the
-    third prefilter search after the last add (auto; "1": with the first; never with the exact kernels, never for an index that is
-    searched once per block), follows later adds (into the tail group, into a new segment), can be switched off on a live handle,
-    and the results are the same bits with and without it -- and the oracle's."""
+    third prefilter search after the last add / reset of an index that has none (auto; "1": with the first; never with the exact
+    kernels, never for an index that is searched once per block), follows later adds at once (into the tail group, into a new
+    segment), is freed when switched off on a live handle, and the results are the same bits with and without it -- and the oracle's."""
     import torch
     from haconvdr_amd.index import FlatIPIndex
     x, q, _ = cases.search_case_inputs("gauss", 0x7B5, 260000, 96)
@@ -1001,13 +1001,23 @@ def test_row_major_copy_for_the_rescoring_is_lazy_optional_and_changes_no_bit(or
     assert_same(D1, I1, *oracle.flat_ip_search(x[:200000], q, 100))
     idx.add(x[200000:200037])                                      # into the tail group of a segment that owns a copy
     idx.add(x[200037:])                                            # ... and a new segment
-    for n in range(3):
+    for n in range(2):                                             # an index that HAS a copy keeps it current: no waiting again
         D2, I2 = idx.search(q, 100)
-        assert ("rescore=rows" in idx.last_plan()) == (n == 2), (n, idx.last_plan())
+        assert "rescore=rows" in idx.last_plan(), (n, idx.last_plan())
+    torch.cuda.synchronize()
+    free_with = torch.cuda.mem_get_info()[0]
     idx.set_option("rescore_rows", "0")
     D3, I3 = idx.search(q, 100)
     assert "rescore=tiles" in idx.last_plan(), idx.last_plan()
     assert_same(D2, I2, D3, I3)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] - free_with > 0.9 * 260000 * 768 * 4       # ... and the copy's memory is back
+    idx.set_option("rescore_rows", "auto")
+    idx.reset()                                                    # after a reset there is no copy: the third search again
+    idx.add(x[:100000])
+    for n in range(3):
+        D5, I5 = idx.search(q, 100)
+        assert ("rescore=rows" in idx.last_plan()) == (n == 2), (n, idx.last_plan())
     sel = np.arange(0, 96, 6)
     assert_same(D2[sel], I2[sel], *oracle.flat_ip_search(x, q[sel], 100))
     idx.set_option("rescore_rows", "1")
