@@ -1370,6 +1370,7 @@ struct hac_encoder {
     // launches, not arithmetic: ~110 kernels for ~0.4 TFLOP.  Their forward is captured ONCE per (B, L, options) into a HIP
     // graph over private input / output buffers and replayed: one graph launch + three small copies per call.
     int graph_mode = -1;                  // -1: small batches without profiling, 0: never
+    int ks_pin_out = 0, ks_pin_down = 0;  // development ("ksplit_pin" = "a/b"): the slices of out-proj / FFN-down pinned (0: by the model)
     int ksplit_mode = -1;                 // -1: split-K of the small-batch RESID GEMMs by tile count, 0: never (tests that compare batches of different sizes bit for bit)
     int plan_ks_out = 1, plan_ks_down = 1;
     struct GraphEntry {
@@ -1499,18 +1500,32 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
     const int bt = big ? 256 : 128;
     const size_t lds = (size_t)4 * bt * 128 + (size_t)(big ? 8 : 4) * 4096;   // 2 stages + per-wave patches
     // Small batches (128^2 tiles): the two RESID GEMMs have only Mp / 128 x 6 output tiles -- 96 for the reference's 4 x 512 query
-    // batch, on 256 CUs -- so their K loop is split until ~1.5 work items per CU exist (slices of at least three k-tiles)
-    // (the split -- i.e. the summation order -- is decided ONCE per hac_encoder_forward* call, from the rows of its first
-    // sub-batch (rows_plan), like the family: a sequence's embedding must not depend on the sub-batch it fell into)
+    // batch, on 256 CUs -- and walk their whole K behind one exposed load latency per k-tile, so their K loop is split into S
+    // slices (GemmArgs::ksplit; ln_stats_rows_kernel adds the slices up).  How far: a slice more saves k-tiles at ~0.6 us each
+    // and costs one more fp32 copy of the rows written and read back, ~1.3 us per 1000 rows; below 8 (K = 3072) / 4 (K = 768)
+    // k-tiles per item nothing is gained, and more items than workgroup slots (2 per CU) is a second round of them.  The minimum
+    // of that model is within 0.3 % of the best of all 28 (S_out, S_down) pairs at 1 x 256, 4 x 256, 4 x 512, 8 x 384 and 8 x 512
+    // (tools/ks_sweep.py on the whole forward, profiles/r05_ksplit_sweep.txt; tools/probes/gemm_small_probe.hip for the kernels
+    // alone).  Round 4's rule -- split until 1.5 items per CU exist -- went 2-3 x too far on the smallest batches: 1 x 256 ran
+    // 4 / 16 slices (0.962 ms) where 3 / 6 is 0.893.
+    // The split -- i.e. the summation order -- is decided ONCE per hac_encoder_forward* call, from the rows of its first
+    // sub-batch (rows_plan), like the family: a sequence's embedding must not depend on the sub-batch it fell into.
     const long Mp_plan = rows_plan > 0 ? (rows_plan + MT - 1) / MT * MT : Mp;
     auto pick_ksplit = [&](int K) {
         if (g8 || big || e->ksplit_mode == 0) return 1;
+        const int KT = K / 64, min_kt = KT >= 48 ? 8 : 4;
+        const int pin = K == H ? e->ks_pin_out : e->ks_pin_down;
+        if (pin > 0 && KT % pin == 0 && KT / pin >= 3) return pin;
         const long tiles = (Mp_plan / 128) * (H / 128);
-        const int KT = K / 64;
         int S = 1;
-        for (int cand : {2, 3, 4, 6, 8, 12, 16}) {
-            if (tiles * S >= e->n_cu * 3 / 2) break;
-            if (KT % cand == 0 && KT / cand >= 3) S = cand;
+        double best = KT * 0.6;
+        for (int cand : {2, 3, 4, 6}) {
+            if (KT % cand || KT / cand < min_kt || tiles * cand > 2L * e->n_cu) continue;
+            const double cost = (double)KT / cand * 0.6 + (cand - 1) * (double)Mp_plan * 1.3e-3;
+            if (cost < best) {
+                best = cost;
+                S = cand;
+            }
         }
         return S;
     };
@@ -2112,6 +2127,12 @@ int hac_encoder_set_option(hac_encoder *e, const char *name, const char *value) 
     } else if (n == "g8_stagger") {
         if (v != "auto" && v != "off") return fail(HAC_ERR_INVALID, "encoder option g8_stagger = '%s': auto | off", value);
         e->g8_stagger = v == "off" ? 0 : -1;
+    } else if (n == "ksplit_pin") {
+        int a = 0, b = 0;
+        if (sscanf(v.c_str(), "%d/%d", &a, &b) != 2 || a < 0 || b < 0 || a > 16 || b > 16) return fail(HAC_ERR_INVALID, "encoder option ksplit_pin = '%s': a/b with 0 <= a, b <= 16", value);
+        e->ks_pin_out = a;
+        e->ks_pin_down = b;
+        drop_graphs(e);
     } else if (n == "ksplit") {
         if (v != "auto" && v != "off") return fail(HAC_ERR_INVALID, "encoder option ksplit = '%s': auto | off", value);
         e->ksplit_mode = v == "off" ? 0 : -1;

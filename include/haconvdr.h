@@ -223,10 +223,11 @@ int hac_encoder_forward_device(hac_encoder *enc, const void *ids_dev, const void
  * of a shape runs plain launches (it sizes the workspaces), the second captures, later ones replay; results are the same bits as
  * with "off" (at most 64 shapes are kept per encoder; beyond that the cache starts over).  Not used while profiling is on or while
  * the caller's stream is itself capturing;
- * "ksplit" = "auto" (default) | "off": with few rows (the classic 128^2 kernels, fewer than ~1.5 output tiles per CU) the two
- * residual GEMMs of a layer split their K loop over 2..16 work items per tile, the partial sums being added in a fixed order by
+ * "ksplit" = "auto" (default) | "off": with few rows (the classic 128^2 kernels) the two residual GEMMs of a layer split their
+ * K loop over 2..6 work items per tile where that pays (by a measured cost model of rows and K), the partial sums being added in a fixed order by
  * the LayerNorm pass behind them: deterministic, but the summation order -- hence the last bits of an embedding -- then depends
  * on the batch's row count (as it does between the "gemm" families); "off" restores one summation order for every small batch;
+ * "ksplit_pin" = "a/b" (development, tools/ks_sweep.py: the slices of out-proj / FFN-down pinned; "0/0" = by the model);
  * "max_tokens" = packed rows per sub-batch (integer >= 4096); "g8_split" = bit mask 0..15 (development: which kernel
  * classes -- bit 0 QKV, 1 out-proj, 2 FFN-up, 3 FFN-down -- run the operand-split loop of the large-batch GEMM, default
  * 15; 0 = round 2's loop: same results bit for bit); "attn_qsplit" = "auto" (default) | "off" (with few sequences the streaming
