@@ -1451,9 +1451,12 @@ int seq_layout(hac_encoder *e, int B, int L, SeqInfo &s) {
 // family: the GEMM family of the whole hac_encoder_forward* call -- FAM_CLASSIC128 / FAM_CLASSIC256 / FAM_GEMM8 -- or -1:
 // decide here, from this (only) sub-batch's rows
 enum { FAM_CLASSIC128 = 0, FAM_GEMM8 = 1, FAM_CLASSIC256 = 2 };
+// 256^2 tiles (gemm8's folded-LayerNorm, bf16-residual path) from this many out-proj tiles on: 9472 rows.  Measured at L = 512
+// (tools/ab_option.py gemm classic 8phase): 16 x 512 classic 2.58 ms against 2.68, 20 x 512 2.91 against 2.75, 24 x 512 3.83 / 3.26.
+constexpr long FAMILY_BIG_TILES = 111;
 int pick_family(const hac_encoder *e, long rows) {
     const long Mp = (rows + MT - 1) / MT * MT;
-    const bool big = (Mp / 256) * (H / 256) >= 128;   // 256^2 tiles once they fill the chip
+    const bool big = (Mp / 256) * (H / 256) >= FAMILY_BIG_TILES;
     if (e->gemm_mode == 1 || (e->gemm_mode < 0 && big)) return FAM_GEMM8;
     return big ? FAM_CLASSIC256 : FAM_CLASSIC128;
 }
@@ -1489,7 +1492,7 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
     // embedding does not depend on which sub-batch it fell into.
     if (family < 0) family = pick_family(e, rows_max);
     const bool g8 = family == FAM_GEMM8;
-    const bool big = family == FAM_CLASSIC256 || (g8 && (Mp / 256) * (H / 256) >= 128);
+    const bool big = family == FAM_CLASSIC256 || (g8 && (Mp / 256) * (H / 256) >= FAMILY_BIG_TILES);
     // (that path's residual stream is bf16 from the embedding rows on: no fp32 copy of them, 3 KB per token less to write)
     embed_ln_kernel<IT><<<dim3(L32 / 4, B), dim3(256), 0, st>>>(ids, L, s, e->word, e->posw, e->typew, e->embg, e->embb, c.ln_eps, c.vocab, g8 ? nullptr : x, xb);
     HAC_HIP(hipGetLastError());
