@@ -1237,6 +1237,7 @@ struct DeviceIndex {
         half_image_unavailable = false;
         row_image_unavailable = false;
         split_searches_since_add = 0;
+        light_searches_since_add = 0;
         HAC_HIP(hipMemsetAsync(ws_norm.p, 0, 16, stream));
         HAC_HIP(hipMemsetAsync(ws_err.p, 0, 16, stream));
         HAC_HIP(hipStreamSynchronize(stream));
@@ -1442,6 +1443,7 @@ struct DeviceIndex {
         half_image_unavailable = false;   // (memory may have been freed since: the next eligible search tries again)
         row_image_unavailable = false;
         split_searches_since_add = 0;
+        light_searches_since_add = 0;
         return HAC_OK;
     }
 
@@ -1779,13 +1781,36 @@ struct DeviceIndex {
     // ---- split-bf16 prefilter + exact rescoring (scan_split.inc): same results, ~3x the query rate when the
     // exact kernels are bound by the fp32 matrix rate.  Worth its fixed cost only for many (query, row) pairs.
     static constexpr int SPLIT_K2 = 256, SPLIT_C2 = 512;
-    bool split_eligible(int64_t nq, int k) const {
-        if (tune.split == 0) return false;   // 0: never, 1: whenever supported (tests), -1: by size
+    // Who takes the prefilter.  It streams the fp16 image -- half the bytes of the fp32 tiles -- so once that image exists it beats
+    // the exact kernels at EVERY query count on a corpus large enough to hide its ~0.18 ms of launches (tools/nq_sweep.py,
+    // profiles/r05_nq_sweep.txt: 6.75M rows 2.1-2.4 ms against 3.4-6.5 ms for 1 ... 64 queries; 1M rows 0.49-0.61 against 0.62-1.06;
+    // break-even near 500k rows for <= 16 queries, 200k for 64, 100k for 256, 50k for 1000; never at 20k).  Three cases:
+    //   * nq >= 48 and nq x rows >= 1e8: the image pays for itself within one or two searches -> built at once (rounds 2-4);
+    //   * otherwise faster by the table above and an image is already there -> used (and kept current across adds);
+    //   * otherwise faster but no image yet (+50 % of the corpus in HBM, one pass over it): an index that keeps being searched
+    //     builds it with its THIRD such search after the last add / reset; an index searched once or twice per block never does.
+    bool split_supported(int k) const {
         // d % 64 == 0 (whole query slices) and at least 12 k-steps per row: the corpus ring runs up to 9 steps ahead and
         // may reach into the NEXT group only
-        if (K4 % 16 != 0 || K4 < 48 || d > HAC_MAX_D || k > SPLIT_K2 - 64 || ntotal < SPLIT_K2) return false;
+        return !(K4 % 16 != 0 || K4 < 48 || d > HAC_MAX_D || k > SPLIT_K2 - 64 || ntotal < SPLIT_K2);
+    }
+    bool half_image_present() const {   // some live segment has one: the rest is brought up to date by ensure_half_image (the new rows only)
+        for (auto &s : segs)
+            if (s.rows > 0 && s.hbuf && s.h_rows > 0) return true;
+        return false;
+    }
+    static constexpr int LIGHT_SEARCHES_BEFORE_IMAGE = 2;
+    int light_searches_since_add = 0;
+    bool split_eligible(int64_t nq, int k) {
+        if (tune.split == 0) return false;   // 0: never, 1: whenever supported (tests), -1: by size
+        if (!split_supported(k)) return false;
         if (tune.split == 1) return true;
-        return nq >= 48 && (double)nq * (double)ntotal >= 1.0e8;
+        const double pairs = (double)nq * (double)ntotal;
+        if (nq >= 48 && pairs >= 1.0e8) return true;
+        const bool faster = ntotal >= 750000 || (nq >= 17 && ntotal >= 500000) || (nq >= 48 && pairs >= 2.5e7 && ntotal >= 40000);
+        if (!faster) return false;
+        if (half_image_present()) return true;
+        return light_searches_since_add++ >= LIGHT_SEARCHES_BEFORE_IMAGE;
     }
 
     int fb_reserve(size_t words) {

@@ -87,7 +87,9 @@ int hac_index_add_device(hac_index *idx, const float *x_dev, int64_t n, void *hi
  *
  * Result contract of every search entry point: score = k-ordered fp32 fma chain, order =
  * (score desc, row asc), NaN scores never returned, short lists padded -FLT_MAX / -1.
- * With many (query, row) pairs (>= 48 queries, >= 1e8 pairs, k <= 192, d % 64 == 0, d >= 192) the
+ * Where it is faster (k <= 192, d % 64 == 0, d >= 192; at once with >= 48 queries and >= 1e8 (query, row) pairs; for fewer --
+ * down to ONE query on >= 750 k rows, >= 17 on >= 500 k, >= 2.5e7 pairs on >= 40 k -- when the fp16 image of the rows exists
+ * already, or from the third such search after the last add / reset on, which builds it: +50 % of the corpus in HBM) the
  * rows are first screened on the fp16 matrix pipe under a proven error bound, the few
  * candidates are rescored exactly and each query's list is certified complete; queries
  * that cannot be certified are searched again by the exact fp32 kernels ("Prefilter with a certificate").

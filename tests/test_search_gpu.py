@@ -439,7 +439,12 @@ def test_cfg3_full_residency_25m_rows(oracle):
     assert all(len(set(r)) == K for r in I[::97].cpu().tolist())
     np.testing.assert_array_equal(I[sel].cpu().numpy(), mI)
     np.testing.assert_array_equal(D[sel].cpu().numpy().astype(np.float64), mD)
-    # the HBM-bound regime (16 queries per corpus pass, scan16_kernel) and the exact many-query kernels give the same bits
+    # few queries per call: with the fp16 image in place "auto" streams it (half the bytes of the fp32 tiles) at any query count ...
+    D16, I16 = idx.search_tensor(q[:16], K)
+    assert idx.last_plan().startswith("split:"), idx.last_plan()
+    assert torch.equal(I16, I[:16]) and torch.equal(D16, D[:16])
+    # ... and the HBM-bound exact kernel (16 queries per corpus pass, scan16_kernel) gives the same bits
+    idx.set_option("split", "0")
     D16, I16 = idx.search_tensor(q[:16], K)
     assert idx.last_plan().startswith("scan16")
     assert torch.equal(I16, I[:16]) and torch.equal(D16, D[:16])
@@ -1029,6 +1034,56 @@ def test_row_major_copy_for_the_rescoring_is_lazy_optional_and_changes_no_bit(or
     from haconvdr_amd._lib import HacError
     with pytest.raises(HacError):
         idx.set_option("rescore_rows", "2")
+
+
+@pytest.mark.gpu
+def test_auto_takes_the_fp16_image_for_few_queries_once_an_index_keeps_being_searched(oracle):
+    """Round 5: the prefilter streams half the bytes of the exact kernels, so on a corpus that hides its fixed cost it is faster at
+    every query count (tools/nq_sweep.py) -- but its fp16 image is +50 % of the corpus and one pass over it.  "auto": at once for many
+    (query, row) pairs as before; for few queries the image is used when it is there, and built by the THIRD such search after the
+    last add / reset (an index searched once or twice per block never pays).  Same bits whichever route."""
+    import torch
+    from haconvdr_amd.index import FlatIPIndex
+    g = torch.Generator(device="cuda").manual_seed(0x5EA)
+    x = torch.randn((800_000, 768), generator=g, device="cuda")
+    q = torch.randn((40, 768), generator=g, device="cuda")
+    idx = FlatIPIndex(768)
+    idx.add_tensor(x[:760_000])
+    ex = FlatIPIndex(768)
+    ex.set_option("split", "0")
+    ex.add_tensor(x[:760_000])
+    D0, I0 = ex.search_tensor(q[:8], 100)
+    for n in range(4):                                             # 760k rows, 8 queries: the exact kernel twice, then the image
+        D, I = idx.search_tensor(q[:8], 100)
+        torch.cuda.synchronize()
+        assert idx.last_plan().startswith("split:" if n >= 2 else "scan16"), (n, idx.last_plan())
+        assert torch.equal(D, D0) and torch.equal(I, I0)
+    D, I = idx.search_tensor(q[:1], 10)                            # the image is there: one query takes it too
+    assert idx.last_plan().startswith("split:"), idx.last_plan()
+    D1, I1 = ex.search_tensor(q[:1], 10)
+    assert torch.equal(D, D1) and torch.equal(I, I1)
+    sel = [0]
+    assert_same(D[sel].cpu().numpy(), I[sel].cpu().numpy(), *oracle.flat_ip_search(x[:760_000].cpu().numpy(), q[:1].cpu().numpy(), 10))
+    idx.add_tensor(x[760_000:])                                    # adds keep an existing image current: no waiting again
+    ex.add_tensor(x[760_000:])
+    D, I = idx.search_tensor(q, 100)
+    assert idx.last_plan().startswith("split:"), idx.last_plan()
+    D2, I2 = ex.search_tensor(q, 100)
+    assert ex.last_plan().startswith("scanq"), ex.last_plan()
+    assert torch.equal(D, D2) and torch.equal(I, I2)
+    idx.reset()                                                    # a reset starts over; a small corpus never takes the route by itself
+    idx.add_tensor(x[:100_000])
+    for n in range(4):
+        D, I = idx.search_tensor(q[:8], 100)
+        assert idx.last_plan().startswith("scan16"), (n, idx.last_plan())
+    del idx                                                        # (a reset keeps the segment's buffers, image included: add() then maintains it)
+    idx = FlatIPIndex(768)
+    idx.add_tensor(x[:520_000])                                    # 17+ queries: from 500k rows on
+    for n in range(3):
+        D, I = idx.search_tensor(q[:32], 100)
+        assert idx.last_plan().startswith("split:" if n >= 2 else "scanq"), (n, idx.last_plan())
+    D, I = idx.search_tensor(q[:8], 100)                           # 520k rows x 8 queries is not faster through the image, there or not
+    assert idx.last_plan().startswith("scan16"), idx.last_plan()
 
 
 @pytest.mark.gpu
