@@ -1370,6 +1370,7 @@ struct hac_encoder {
     // launches, not arithmetic: ~110 kernels for ~0.4 TFLOP.  Their forward is captured ONCE per (B, L, options) into a HIP
     // graph over private input / output buffers and replayed: one graph launch + three small copies per call.
     int graph_mode = -1;                  // -1: small batches without profiling, 0: never
+    int attn_qs_pin = 0;                  // development ("attn_qs_pin" = 1 | 2 | 4 | 8 | 16; 0: by the rule)
     int ks_pin_out = 0, ks_pin_down = 0;  // development ("ksplit_pin" = "a/b"): the slices of out-proj / FFN-down pinned (0: by the model)
     int ksplit_mode = -1;                 // -1: split-K of the small-batch RESID GEMMs by tile count, 0: never (tests that compare batches of different sizes bit for bit)
     int plan_ks_out = 1, plan_ks_down = 1;
@@ -1629,6 +1630,7 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
         // (streaming kernels: few sequences -> an item's query rows go to 2 or 4 workgroups while B * NH * qsplit items still fit the CUs)
         int att_qs = 1;
         while (e->attn_qsplit != 0 && att_qs < 16 && (long)B * NH * att_qs * 2 <= e->n_cu) att_qs *= 2;
+        if (e->attn_qs_pin > 0) att_qs = e->attn_qs_pin;   // development (tools/ks_sweep.py attn)
         const bool att_one = att_qs > 1 && L32 > 256;   // few sequences: one launch (an empty second one is 5 us of a ~100-us layer)
         AttnArgs a{q, k, vt, ctx, s, last ? 1 : 0, att_qs, att_one ? 1 : 0};
         // sequences of <= 256 rows: 4-wave workgroups; longer ones: 8-wave workgroups (each skips the other's)
@@ -2130,6 +2132,10 @@ int hac_encoder_set_option(hac_encoder *e, const char *name, const char *value) 
     } else if (n == "g8_stagger") {
         if (v != "auto" && v != "off") return fail(HAC_ERR_INVALID, "encoder option g8_stagger = '%s': auto | off", value);
         e->g8_stagger = v == "off" ? 0 : -1;
+    } else if (n == "attn_qs_pin") {
+        if (v != "0" && v != "1" && v != "2" && v != "4" && v != "8" && v != "16") return fail(HAC_ERR_INVALID, "encoder option attn_qs_pin = '%s': 0 | 1 | 2 | 4 | 8 | 16", value);
+        e->attn_qs_pin = atoi(v.c_str());
+        drop_graphs(e);
     } else if (n == "ksplit_pin") {
         int a = 0, b = 0;
         if (sscanf(v.c_str(), "%d/%d", &a, &b) != 2 || a < 0 || b < 0 || a > 16 || b > 16) return fail(HAC_ERR_INVALID, "encoder option ksplit_pin = '%s': a/b with 0 <= a, b <= 16", value);

@@ -230,6 +230,7 @@ int hac_encoder_forward_device(hac_encoder *enc, const void *ids_dev, const void
  * the LayerNorm pass behind them: deterministic, but the summation order -- hence the last bits of an embedding -- then depends
  * on the batch's row count (as it does between the "gemm" families); "off" restores one summation order for every small batch;
  * "ksplit_pin" = "a/b" (development, tools/ks_sweep.py: the slices of out-proj / FFN-down pinned; "0/0" = by the model);
+ * "attn_qs_pin" = "0" | "1" | "2" | "4" | "8" | "16" (development, tools/opt_sweep.py: the streaming attention's query split pinned; "0" = by the rule);
  * "max_tokens" = packed rows per sub-batch (integer >= 4096); "g8_split" = bit mask 0..15 (development: which kernel
  * classes -- bit 0 QKV, 1 out-proj, 2 FFN-up, 3 FFN-down -- run the operand-split loop of the large-batch GEMM, default
  * 15; 0 = round 2's loop: same results bit for bit); "attn_qsplit" = "auto" (default) | "off" (with few sequences the streaming
