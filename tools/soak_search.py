@@ -1,4 +1,5 @@
-"""Development: soak of the search -- the prefilter path (split=1) against the exact fp32 kernels (split=0) over random corpora, query sets and
+"""Development: soak of the search -- the prefilter path (split=1) and what auto decides (its fp16 image appears with a third light search, or at once
+for many pairs) against the exact fp32 kernels (split=0) over random corpora, query sets and
 value ranges, a fresh index per case (every lifetime recycles device memory): bit-exact ids and scores, progress every 5 cases.
   python tools/soak_search.py [seed] [seconds]"""
 import os, sys, time
@@ -9,7 +10,7 @@ import torch
 from haconvdr_amd.index import FlatIPIndex
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 240.0
-t0 = time.time(); n_cases = 0; n_split = 0; n_multi = 0
+t0 = time.time(); n_cases = 0; n_split = 0; n_multi = 0; n_auto_split = 0
 while time.time() - t0 < budget:
     n = int(rng.choice([20_000, 50_001, 130_000, 400_000, 1_000_000]))
     nq = int(rng.choice([1, 40, 130, 257, 1000, 1500]))
@@ -25,7 +26,7 @@ while time.time() - t0 < budget:
         x = torch.randn((n, 8), generator=g, device="cuda") @ torch.randn((8, 768), generator=g, device="cuda")
     # several searches per index lifetime: workspaces keep what the previous search left behind the counts of the next
     qsets = []
-    for rep in range(int(rng.integers(1, 4))):
+    for rep in range(int(rng.integers(1, 6))):   # (up to five: "auto" builds its fp16 image with the third light search of an index)
         nq_r = nq if rep == 0 else int(rng.choice([1, 40, 130, 257, 1000]))
         qr = torch.randn((nq_r, 768), generator=g, device="cuda")
         mode = rng.choice(["plain", "plain", "huge", "nan_row", "scaled"])
@@ -42,10 +43,10 @@ while time.time() - t0 < budget:
     cuts = str(rng.choice(["auto", "100,400", "50,120", "300,600"]))
     seed_groups = str(rng.choice(["0", "768", "4096"]))
     rescore_rows = str(rng.choice(["auto", "0", "1", "1"]))   # round 5: the rescoring's row-major copy (auto: from the third search of an index on)
-    for split in ("1", "0"):
+    for split in ("1", "0", "auto"):
         idx = FlatIPIndex(768)
         idx.set_option("split", split)
-        if split == "1":
+        if split != "0":
             idx.set_option("scan_passes", passes)
             idx.set_option("scan_pass_cuts", cuts)
             idx.set_option("seed_groups_max", seed_groups)
@@ -56,13 +57,14 @@ while time.time() - t0 < budget:
     ok = True
     for qr in qsets:
         res = []
-        for split in ("1", "0"):
+        for split in ("1", "0", "auto"):
             D, I = idxs[split].search_tensor(qr, k)
             torch.cuda.synchronize()
             idxs[split].check_status()   # a scan that gave up at its pass bound is HAC_ERR_INTERNAL here, not a hang
             res.append((D.clone(), I.clone(), idxs[split].last_plan()))
         # NaN scores compare unequal: ids are what is compared there
-        same = torch.equal(res[0][1], res[1][1]) and torch.equal(torch.nan_to_num(res[0][0], nan=0.0), torch.nan_to_num(res[1][0], nan=0.0))
+        same = all(torch.equal(res[j][1], res[1][1]) and torch.equal(torch.nan_to_num(res[j][0], nan=0.0), torch.nan_to_num(res[1][0], nan=0.0)) for j in (0, 2))
+        n_auto_split += res[2][2].startswith("split:")
         ok = ok and same
         if not same:
             bad = (res[0][1] != res[1][1]).nonzero()
@@ -74,4 +76,4 @@ while time.time() - t0 < budget:
         print(f'{n_cases} cases ok, {time.time() - t0:.0f} s', flush=True)
     n_split += res[0][2].startswith("split:")
     n_multi += res[0][2].startswith("split:") and "passes=1 " not in res[0][2]
-print(f"soak ok: {n_cases} cases ({n_split} through the prefilter, {n_multi} of them in several passes) in {time.time() - t0:.0f} s", flush=True)
+print(f"soak ok: {n_cases} cases ({n_split} through the prefilter, {n_multi} of them in several passes; {n_auto_split} searches of the auto index took the prefilter) in {time.time() - t0:.0f} s", flush=True)
