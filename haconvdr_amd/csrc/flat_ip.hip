@@ -1346,19 +1346,37 @@ struct DeviceIndex {
             if (sg.rows > 0 && !(sg.rbuf && sg.r_rows == sg.rows)) all = false;
         return all ? "rows" : "tiles";
     }
+    // (a search that is being captured into a HIP graph must not allocate, free or synchronize: the lazy images are neither
+    // built nor dropped by it -- the capture records what the call before it ran)
+    static bool stream_is_capturing(hipStream_t st) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        return cs != hipStreamCaptureStatusNone;
+    }
     int ensure_row_image(hipStream_t st) {
         const bool allowed = tune.rescore_rows == 1 || (tune.rescore_rows < 0 && ntotal <= RESCORE_ROWS_MAX);
+        const bool capturing = stream_is_capturing(st);
         if (!allowed) {   // switched off on a live handle, or grown past the size that gets one: the copies go (hipFree waits for their readers)
             for (auto &s : segs) {
                 if (!s.rbuf) continue;
-                HAC_HIP(hipFree(s.rbuf));
-                s.rbuf = nullptr;
+                if (!capturing) {
+                    HAC_HIP(hipFree(s.rbuf));
+                    s.rbuf = nullptr;
+                }
                 s.r_rows = 0;
                 segs_dirty = true;
             }
             return HAC_OK;
         }
         if (row_image_unavailable) return HAC_OK;
+        if (capturing) {   // use what is current, build nothing
+            bool need = false;
+            for (auto &s : segs) need |= s.rows > 0 && !(s.rbuf && s.r_rows == s.rows);
+            if (need) return HAC_OK;
+        }
         if (tune.rescore_rows < 0) {
             // an index that HAS a copy keeps it current (an add then costs the new rows once more, on the device); one that has
             // none waits for its third search
@@ -1801,7 +1819,7 @@ struct DeviceIndex {
     }
     static constexpr int LIGHT_SEARCHES_BEFORE_IMAGE = 2;
     int light_searches_since_add = 0;
-    bool split_eligible(int64_t nq, int k) {
+    bool split_eligible(int64_t nq, int k, bool capturing = false) {
         if (tune.split == 0) return false;   // 0: never, 1: whenever supported (tests), -1: by size
         if (!split_supported(k)) return false;
         if (tune.split == 1) return true;
@@ -1810,6 +1828,7 @@ struct DeviceIndex {
         const bool faster = ntotal >= 750000 || (nq >= 17 && ntotal >= 500000) || (nq >= 48 && pairs >= 2.5e7 && ntotal >= 40000);
         if (!faster) return false;
         if (half_image_present()) return true;
+        if (capturing) return false;          // (a captured search builds nothing: see stream_is_capturing)
         return light_searches_since_add++ >= LIGHT_SEARCHES_BEFORE_IMAGE;
     }
 
@@ -2086,7 +2105,7 @@ struct DeviceIndex {
             if (((uintptr_t)q_dev & 15) != 0) return fail(HAC_ERR_INVALID, "search: query pointer must be 16-byte aligned");
             if ((uint64_t)pos_base + (uint64_t)ntotal > 0xFFFFFFFFull) return fail(HAC_ERR_UNSUPPORTED, "row positions exceed 32 bits");
         }
-        if (nq > 0 && ntotal > 0 && split_eligible(nq, k) && !(tune.split < 0 && half_image_unavailable)) {
+        if (nq > 0 && ntotal > 0 && split_eligible(nq, k, stream_is_capturing(st)) && !(tune.split < 0 && half_image_unavailable)) {
             const int rc_img = ensure_half_image(st);
             if (rc_img == HAC_OK) return search_keys_split(q_dev, nq, k, keys_out, pos_base, st, 0, tune.split_decide < 0 ? device_entry : tune.split_decide == 1);
             if (rc_img != HAC_ERR_OOM || tune.split == 1) return rc_img;
