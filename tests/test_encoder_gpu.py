@@ -549,11 +549,12 @@ def test_options_outside_the_documented_set_are_errors():
     from haconvdr_amd.index import FlatIPIndex
     enc = encoder(2)
     for name, value in (("gemm", "8-phase"), ("gemm", ""), ("attn", "two-pass"), ("max_tokens", "12"), ("max_tokens", "lots"), ("nope", "1"),
-                        ("graph", "maybe"), ("ksplit", "2"), ("g8_stagger", "on")):
+                        ("graph", "maybe"), ("ksplit", "2"), ("g8_stagger", "on"), ("ksplit_pin", "2"), ("ksplit_pin", "2/x"), ("ksplit_pin", "17/1"),
+                        ("attn_qs_pin", "3"), ("attn_qs_pin", "on")):
         with pytest.raises(HacError):
             enc.set_option(name, value)
     for name, value in (("gemm", "auto"), ("attn", "stream"), ("graph", "off"), ("graph", "auto"), ("ksplit", "off"), ("ksplit", "auto"),
-                        ("g8_stagger", "off"), ("g8_stagger", "auto")):
+                        ("g8_stagger", "off"), ("g8_stagger", "auto"), ("ksplit_pin", "2/4"), ("ksplit_pin", "0/0"), ("attn_qs_pin", "4"), ("attn_qs_pin", "0")):
         enc.set_option(name, value)
     idx = FlatIPIndex(768)
     for name, value in (("split", "on"), ("split_terms", "2"), ("force_scan16", "yes"), ("scanq_nt", "5"), ("scanq_waves", "6"),
