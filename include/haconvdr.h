@@ -102,8 +102,10 @@ int hac_index_add_device(hac_index *idx, const float *x_dev, int64_t n, void *hi
  * and never synchronize or read back: they can be captured into a HIP graph once workspaces,
  * the segment table (re-uploaded by the first search after an add / reset, which does
  * synchronize once) and the fp16 image exist.  That image (+50 % of the corpus bytes in HBM)
- * is built by the first search that takes the screen; an index that never does (few queries
- * per call, or split = "0") never allocates it.  With split = "auto", when the image does not fit beside the corpus the
+ * is built by the first search that takes the screen and lives as long as the segment it belongs to (reset() keeps both;
+ * destroying the handle frees them); an index that never takes it (small, searched once or twice per add, or split = "0")
+ * never allocates it.  A search that is being captured never builds it (nor the rescoring's row-major copy): it runs what
+ * the call before it ran.  With split = "auto", when the image does not fit beside the corpus the
  * exact fp32 kernels answer instead (same bits) and no search tries again until the next add / reset; split = "1"
  * reports HAC_ERR_OOM.
  * Before capturing a *_device search into a graph, run one search of the LARGEST shape (nq, k) you will capture: a call that
