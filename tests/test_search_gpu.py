@@ -1100,6 +1100,22 @@ def test_auto_takes_the_fp16_image_for_few_queries_once_an_index_keeps_being_sea
         assert idx.last_plan().startswith("split:" if n >= 2 else "scanq"), (n, idx.last_plan())
     D, I = idx.search_tensor(q[:8], 100)                           # 520k rows x 8 queries is not faster through the image, there or not
     assert idx.last_plan().startswith("scan16"), idx.last_plan()
+    # two in-process shards (faiss shard=True): each decides for its own rows (2 x 800k, every row twice: ties across the shards)
+    del idx, ex
+    torch.cuda.empty_cache()
+    idx, ex = FlatIPIndex(768, devices=(0, 0)), FlatIPIndex(768, devices=(0, 0))
+    ex.set_option("split", "0")
+    xh, qh = x.cpu().numpy(), q[:8].cpu().numpy()                  # (a multi-device index takes host rows, as faiss does)
+    for ix in (idx, ex):
+        ix.add(xh)
+        ix.add(xh)
+    assert idx.ntotal == 1_600_000
+    Dx, Ix = ex.search(qh, 100)
+    assert bool((Ix[:, 0::2] + 800_000 == Ix[:, 1::2]).all())      # (a row and its copy 800k later tie: the earlier one first)
+    for n in range(4):
+        D, I = idx.search(qh, 100)
+        assert idx.last_plan().startswith("split:" if n >= 2 else "scan16"), (n, idx.last_plan())
+        assert np.array_equal(D, Dx) and np.array_equal(I, Ix)
 
 
 @pytest.mark.gpu
