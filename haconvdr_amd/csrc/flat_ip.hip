@@ -984,6 +984,7 @@ struct DeviceIndex {
         bool no_p8 = false;
         int seed_groups_max = 0;         // cap of the seeding pass of the prefilter scan, in 64-row groups; 0 = 14 sqrt(groups)
         int split_decide = -1;           // who reads the certificates: -1 by entry point (host API: host, *_device: device), 0 host, 1 device
+        bool image_eager = false;        // "fp16_image" = "eager": the fp16 image is written by add() (new segments), not by a later search
         int rescore_rows = -1;           // row-major copy for the rescoring: -1 by size (<= RESCORE_ROWS_MAX rows), 0 never, 1 whenever it can be allocated
         int debug_max_pass = 0;          // tests: pass bound of the candidate loops (0 = the kernels' own, which no legal input reaches)
         int scan_passes = 0;             // prefilter scan: 0 by size, 1..5 pins the number of passes (threshold refreshes between them)
@@ -1069,6 +1070,9 @@ struct DeviceIndex {
         } else if (n == "scan_passes") {
             if (!one_of({"auto", "1", "2", "3", "4", "5"})) return HAC_ERR_INVALID;
             tune.scan_passes = v == "auto" ? 0 : atoi(v.c_str());
+        } else if (n == "fp16_image") {
+            if (!one_of({"lazy", "eager"})) return HAC_ERR_INVALID;
+            tune.image_eager = v == "eager";
         } else if (n == "rescore_rows") {
             if (!one_of({"0", "1", "auto"})) return HAC_ERR_INVALID;
             tune.rescore_rows = v == "0" ? 0 : (v == "1" ? 1 : -1);
@@ -1445,6 +1449,16 @@ struct DeviceIndex {
                 HAC_TRY(new_segment(std::max(n, reserve_hint) - done, st));
             }
             Segment &s = segs.back();
+            if (tune.image_eager && !s.hbuf && s.rows == 0 && tune.split != 0) {
+                // option "fp16_image" = "eager": a resident index that will be searched with few queries per call gets its image
+                // while the rows are tiled (the add is bound by the rows' arrival, the +50 % of writes ride along) instead of by
+                // its third search.  Best effort: without room the lazy route decides later.
+                if (hipMalloc((void **)&s.hbuf, (size_t)s.cap_rows * d * 2) != hipSuccess) {
+                    s.hbuf = nullptr;
+                    (void)hipGetLastError();
+                }
+                s.h_rows = 0;
+            }
             const int64_t m = std::min(n - done, s.cap_rows - s.rows);
             const long row0 = (long)s.rows;
             const long g_lo = row0 / GROUP_ROWS, g_hi = (row0 + m + GROUP_ROWS - 1) / GROUP_ROWS;

@@ -146,6 +146,9 @@ int hac_index_last_status(hac_index *idx);
  * far between them; auto: 3 from 1.6M rows, 4 from 8.4M), "scan_pass_cuts" = "auto" | "a,b" (where the first two passes end, in
  * thousandths of the rows; auto: the first after ~6k 64-row groups, the others in geometric progression towards the corpus), "debug_max_pass" = integer >= 0 (tests: the pass bound of the
  * candidate loops; 0 = the bound no legal input reaches),
+ * "fp16_image" = "lazy" (default) | "eager": when the fp16 image of the rows (what the prefilter streams) is made: by the first
+ * search that wants it, or by add() while it tiles the rows of a new segment (a resident index that will serve few queries per call
+ * is then fast from its first search; best effort, +50 % of the corpus in HBM either way),
  * "rescore_rows" = "auto" | "0" | "1": the prefilter's exact rescoring reads ~130 scattered rows per query; out of the T64 tiles
  * that is one useful 16-byte piece per 64-byte sector.  Small indexes (auto: <= 12M rows) therefore keep their rows once more,
  * row-major, for the rescoring alone (+100 % of a small corpus, built lazily by the THIRD prefilter search after the last add /

@@ -1100,6 +1100,23 @@ def test_auto_takes_the_fp16_image_for_few_queries_once_an_index_keeps_being_sea
         assert idx.last_plan().startswith("split:" if n >= 2 else "scanq"), (n, idx.last_plan())
     D, I = idx.search_tensor(q[:8], 100)                           # 520k rows x 8 queries is not faster through the image, there or not
     assert idx.last_plan().startswith("scan16"), idx.last_plan()
+    # option "fp16_image" = "eager": add() writes the image while it tiles the rows: the FIRST few-query search takes it
+    del idx
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free0 = torch.cuda.mem_get_info()[0]
+    idx = FlatIPIndex(768)
+    idx.set_option("fp16_image", "eager")
+    idx.add_tensor(x[:760_000])
+    torch.cuda.synchronize()
+    assert free0 - torch.cuda.mem_get_info()[0] > 1.4 * 760_000 * 768 * 4          # tiles + image
+    D, I = idx.search_tensor(q[:8], 100)
+    assert idx.last_plan().startswith("split:"), idx.last_plan()
+    assert torch.equal(D, D0) and torch.equal(I, I0)
+    from haconvdr_amd._lib import HacError
+    with pytest.raises(HacError):
+        idx.set_option("fp16_image", "yes")
+    idx.set_option("fp16_image", "lazy")
     # two in-process shards (faiss shard=True): each decides for its own rows (2 x 800k, every row twice: ties across the shards)
     del idx, ex
     torch.cuda.empty_cache()
