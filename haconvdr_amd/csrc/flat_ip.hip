@@ -1833,7 +1833,8 @@ struct DeviceIndex {
     }
     static constexpr int LIGHT_SEARCHES_BEFORE_IMAGE = 2;
     int light_searches_since_add = 0;
-    bool split_eligible(int64_t nq, int k, bool capturing = false) {
+    // (not a pure predicate: a light search of an index without an image counts towards building one)
+    bool decide_prefilter(int64_t nq, int k, bool capturing = false) {
         if (tune.split == 0) return false;   // 0: never, 1: whenever supported (tests), -1: by size
         if (!split_supported(k)) return false;
         if (tune.split == 1) return true;
@@ -2119,7 +2120,7 @@ struct DeviceIndex {
             if (((uintptr_t)q_dev & 15) != 0) return fail(HAC_ERR_INVALID, "search: query pointer must be 16-byte aligned");
             if ((uint64_t)pos_base + (uint64_t)ntotal > 0xFFFFFFFFull) return fail(HAC_ERR_UNSUPPORTED, "row positions exceed 32 bits");
         }
-        if (nq > 0 && ntotal > 0 && split_eligible(nq, k, stream_is_capturing(st)) && !(tune.split < 0 && half_image_unavailable)) {
+        if (nq > 0 && ntotal > 0 && decide_prefilter(nq, k, stream_is_capturing(st)) && !(tune.split < 0 && half_image_unavailable)) {
             const int rc_img = ensure_half_image(st);
             if (rc_img == HAC_OK) return search_keys_split(q_dev, nq, k, keys_out, pos_base, st, 0, tune.split_decide < 0 ? device_entry : tune.split_decide == 1);
             if (rc_img != HAC_ERR_OOM || tune.split == 1) return rc_img;
