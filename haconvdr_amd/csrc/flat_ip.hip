@@ -984,6 +984,7 @@ struct DeviceIndex {
         bool no_p8 = false;
         int seed_groups_max = 0;         // cap of the seeding pass of the prefilter scan, in 64-row groups; 0 = 14 sqrt(groups)
         int split_decide = -1;           // who reads the certificates: -1 by entry point (host API: host, *_device: device), 0 host, 1 device
+        bool no_halfq = false;           // development ("scan_halfq" = "0"): few-query searches run the full-tile instantiation
         bool image_eager = false;        // "fp16_image" = "eager": the fp16 image is written by add() (new segments), not by a later search
         int rescore_rows = -1;           // row-major copy for the rescoring: -1 by size (<= RESCORE_ROWS_MAX rows), 0 never, 1 whenever it can be allocated
         int debug_max_pass = 0;          // tests: pass bound of the candidate loops (0 = the kernels' own, which no legal input reaches)
@@ -1070,6 +1071,9 @@ struct DeviceIndex {
         } else if (n == "scan_passes") {
             if (!one_of({"auto", "1", "2", "3", "4", "5"})) return HAC_ERR_INVALID;
             tune.scan_passes = v == "auto" ? 0 : atoi(v.c_str());
+        } else if (n == "scan_halfq") {
+            if (!one_of({"0", "1"})) return HAC_ERR_INVALID;
+            tune.no_halfq = v == "0";
         } else if (n == "fp16_image") {
             if (!one_of({"lazy", "eager"})) return HAC_ERR_INVALID;
             tune.image_eager = v == "eager";
@@ -1166,7 +1170,8 @@ struct DeviceIndex {
             for (const void *f : fq) HAC_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
             HAC_HIP(hipFuncSetAttribute((const void *)sample_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * 1024)));
             const void *fh[] = {(const void *)scanh_kernel<1, false>, (const void *)scanh_kernel<3, false>,
-                                (const void *)scanh_kernel<1, true>, (const void *)scanh_kernel<3, true>};
+                                (const void *)scanh_kernel<1, true>, (const void *)scanh_kernel<3, true>,
+                                (const void *)scanh_kernel<1, false, true>, (const void *)scanh_kernel<1, true, true>};
             for (const void *f : fh) HAC_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
             attr_done[device] = true;
         }
@@ -1912,6 +1917,7 @@ struct DeviceIndex {
         sp.thr_is_approx = 1;
         long P_last = 0;
         int n_qtiles_last = 0, seeded = 0, n_chunks = 0, passes_last = 1;
+        bool halfq_last = false;
         for (int64_t off = 0; off < nq; off += chunk, ++n_chunks) {
             const int64_t n = std::min<int64_t>(chunk, nq - off);
             const float *qc = q_dev + (size_t)off * d;
@@ -1948,6 +1954,8 @@ struct DeviceIndex {
             // 1M rows, then ~14 sqrt(G) groups (measured optimum at 6.75M / 10M / 25M rows: 4.1k / 5.1k / 10k groups;
             // a sixteenth of 25M rows cost 1.5 ms more per 1000-query search, 2k groups 11 ms more).
             const dim3 grid((unsigned)P, (unsigned)n_qtiles), blk(SH_W * 64);
+            // one tile of at most 128 real queries: the instantiation without the upper 16-query tiles' matrix work (scanh_kernel, HALFQ)
+            const bool halfq = terms == 1 && SH_M16 && n_qtiles == 1 && n <= SH_NQ / 2 && !tune.no_halfq;
             const u32 round_groups = (u32)P * SH_GPR;
             // (a scan that will be cut into passes refreshes its thresholds after ~6k groups anyway: 1024 groups of seeding do)
             u32 probe_bounds[MAX_PASSES + 1];
@@ -1962,6 +1970,7 @@ struct DeviceIndex {
                 a.thr_init = nullptr;
                 sp.maxima = (float *)ws_seedkeys.p;
                 if (terms == 3) scanh_kernel<3, true><<<grid, blk, lds, st>>>(a, sp);
+                else if (halfq) scanh_kernel<1, true, true><<<grid, blk, lds, st>>>(a, sp);
                 else scanh_kernel<1, true><<<grid, blk, lds, st>>>(a, sp);
                 HAC_HIP(hipGetLastError());
                 kth_select_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>((const float *)ws_seedkeys.p, S, K2, (float *)ws_thr.p);
@@ -1981,6 +1990,7 @@ struct DeviceIndex {
                 a.g_first = bounds[ps];
                 a.n_items = bounds[ps + 1] - bounds[ps];
                 if (terms == 3) scanh_kernel<3, false><<<grid, blk, lds, st>>>(a, sp);
+                else if (halfq) scanh_kernel<1, false, true><<<grid, blk, lds, st>>>(a, sp);
                 else scanh_kernel<1, false><<<grid, blk, lds, st>>>(a, sp);
                 HAC_HIP(hipGetLastError());
                 if (ps + 1 < n_pass) {   // refresh: ws_thr[q] = max(ws_thr[q], K2-th best s~ so far)
@@ -1992,6 +2002,7 @@ struct DeviceIndex {
             }
             a.g_first = 0;
             passes_last = n_pass;
+            halfq_last = halfq;
             if (profiling) {
                 HAC_HIP(hipEventRecord(ev_pool[ev_used].second, st));
                 ++ev_used;
@@ -2044,8 +2055,8 @@ struct DeviceIndex {
                                                                                                   (int)nq, k, keys_out, nf_dev);
             HAC_HIP(hipGetLastError());
             ++split_searches;
-            snprintf(plan_head, sizeof plan_head, "split: scanh_kernel<%d> grid=(%ld,%d) NQ=%d K2=%d chunks=%d lds=%zu seed=%d passes=%d rescore=%s", terms, P_last,
-                     n_qtiles_last, SH_NQ, K2, n_chunks, lds, seeded, passes_last, rescore_from());
+            snprintf(plan_head, sizeof plan_head, "split: scanh_kernel<%d> grid=(%ld,%d) NQ=%d K2=%d chunks=%d lds=%zu seed=%d passes=%d rescore=%s%s", terms, P_last,
+                     n_qtiles_last, SH_NQ, K2, n_chunks, lds, seeded, passes_last, rescore_from(), halfq_last ? " tiles=half" : "");
             snprintf(last_plan, sizeof last_plan, "%s fallback=device-side/%lld", plan_head, (long long)nq);
             const int slot = plan_slot();
             HAC_HIP(hipMemcpyAsync(h_plan + 2 * slot, ws_stat.p, 8, hipMemcpyDeviceToHost, st));
@@ -2062,8 +2073,8 @@ struct DeviceIndex {
         std::memcpy(&maxratio, &h_fb[1], 4);
         if (level == 0) ++split_searches;
         char plan_here[sizeof last_plan];
-        snprintf(plan_here, sizeof plan_here, "split: scanh_kernel<%d> grid=(%ld,%d) NQ=%d K2=%d chunks=%d lds=%zu seed=%d passes=%d rescore=%s fallback=%u/%lld err/bound=%.3g",
-                 terms, P_last, n_qtiles_last, SH_NQ, K2, n_chunks, lds, seeded, passes_last, rescore_from(), nfail, (long long)nq, (double)maxratio);
+        snprintf(plan_here, sizeof plan_here, "split: scanh_kernel<%d> grid=(%ld,%d) NQ=%d K2=%d chunks=%d lds=%zu seed=%d passes=%d rescore=%s%s fallback=%u/%lld err/bound=%.3g",
+                 terms, P_last, n_qtiles_last, SH_NQ, K2, n_chunks, lds, seeded, passes_last, rescore_from(), halfq_last ? " tiles=half" : "", nfail, (long long)nq, (double)maxratio);
         std::memcpy(last_plan, plan_here, sizeof last_plan);
         plan_text_slot = -1;
         if (nfail == 0) return HAC_OK;

@@ -559,11 +559,11 @@ def test_options_outside_the_documented_set_are_errors():
     idx = FlatIPIndex(768)
     for name, value in (("split", "on"), ("split_terms", "2"), ("force_scan16", "yes"), ("scanq_nt", "5"), ("scanq_waves", "6"),
                         ("scan_no_p8", "2"), ("seed_groups_max", "-3"), ("seed_groups_max", "many"), ("nope", "1"),
-                        ("scan_passes", "0"), ("scan_passes", "6"), ("scan_pass_cuts", "900,100"), ("scan_pass_cuts", "30"), ("scan_pass_cuts", "0,500")):
+                        ("scan_passes", "0"), ("scan_passes", "6"), ("scan_halfq", "2"), ("fp16_image", "now"), ("scan_pass_cuts", "900,100"), ("scan_pass_cuts", "30"), ("scan_pass_cuts", "0,500")):
         with pytest.raises(HacError):
             idx.set_option(name, value)
     for name, value in (("split", "auto"), ("split_terms", "1"), ("scanq_nt", "0"), ("scanq_waves", "8"), ("seed_groups_max", "0"),
-                        ("scan_passes", "5"), ("scan_passes", "auto"), ("scan_pass_cuts", "30,200"), ("scan_pass_cuts", "auto")):
+                        ("scan_passes", "5"), ("scan_passes", "auto"), ("scan_halfq", "1"), ("fp16_image", "lazy"), ("scan_pass_cuts", "30,200"), ("scan_pass_cuts", "auto")):
         idx.set_option(name, value)
 
 

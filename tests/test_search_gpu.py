@@ -1074,6 +1074,12 @@ def test_auto_takes_the_fp16_image_for_few_queries_once_an_index_keeps_being_sea
         torch.cuda.synchronize()
         assert idx.last_plan().startswith("split:" if n >= 3 else "scan16"), (n, idx.last_plan())
         assert torch.equal(D, D0) and torch.equal(I, I0)
+    assert "tiles=half" in idx.last_plan(), idx.last_plan()        # <= 128 queries: the instantiation without the empty query tiles' matrix work
+    idx.set_option("scan_halfq", "0")                              # ... and the full-tile form gives the same bits
+    D, I = idx.search_tensor(q[:8], 100)
+    assert "tiles=half" not in idx.last_plan() and idx.last_plan().startswith("split:"), idx.last_plan()
+    assert torch.equal(D, D0) and torch.equal(I, I0)
+    idx.set_option("scan_halfq", "1")
     D, I = idx.search_tensor(q[:1], 10)                            # the image is there: one query takes it too
     assert idx.last_plan().startswith("split:"), idx.last_plan()
     D1, I1 = ex.search_tensor(q[:1], 10)
