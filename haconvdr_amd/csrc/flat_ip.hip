@@ -1171,7 +1171,8 @@ struct DeviceIndex {
             HAC_HIP(hipFuncSetAttribute((const void *)sample_scores_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * 1024)));
             const void *fh[] = {(const void *)scanh_kernel<1, false>, (const void *)scanh_kernel<3, false>,
                                 (const void *)scanh_kernel<1, true>, (const void *)scanh_kernel<3, true>,
-                                (const void *)scanh_kernel<1, false, true>, (const void *)scanh_kernel<1, true, true>};
+                                (const void *)scanh_kernel<1, false, 8>, (const void *)scanh_kernel<1, true, 8>,
+                                (const void *)scanh_kernel<1, false, 4>, (const void *)scanh_kernel<1, true, 4>};
             for (const void *f : fh) HAC_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
             attr_done[device] = true;
         }
@@ -1917,7 +1918,7 @@ struct DeviceIndex {
         sp.thr_is_approx = 1;
         long P_last = 0;
         int n_qtiles_last = 0, seeded = 0, n_chunks = 0, passes_last = 1;
-        bool halfq_last = false;
+        int qt_act_last = 16;
         for (int64_t off = 0; off < nq; off += chunk, ++n_chunks) {
             const int64_t n = std::min<int64_t>(chunk, nq - off);
             const float *qc = q_dev + (size_t)off * d;
@@ -1954,8 +1955,9 @@ struct DeviceIndex {
             // 1M rows, then ~14 sqrt(G) groups (measured optimum at 6.75M / 10M / 25M rows: 4.1k / 5.1k / 10k groups;
             // a sixteenth of 25M rows cost 1.5 ms more per 1000-query search, 2k groups 11 ms more).
             const dim3 grid((unsigned)P, (unsigned)n_qtiles), blk(SH_W * 64);
-            // one tile of at most 128 real queries: the instantiation without the upper 16-query tiles' matrix work (scanh_kernel, HALFQ)
-            const bool halfq = terms == 1 && SH_M16 && n_qtiles == 1 && n <= SH_NQ / 2 && !tune.no_halfq;
+            // one tile of at most 128 / 64 real queries: the instantiations without the empty 16-query tiles' matrix work (scanh_kernel, QT_ACT)
+            const bool few = terms == 1 && SH_M16 && n_qtiles == 1 && !tune.no_halfq;
+            const int qt_act = few && n <= SH_NQ / 4 ? 4 : few && n <= SH_NQ / 2 ? 8 : 16;
             const u32 round_groups = (u32)P * SH_GPR;
             // (a scan that will be cut into passes refreshes its thresholds after ~6k groups anyway: 1024 groups of seeding do)
             u32 probe_bounds[MAX_PASSES + 1];
@@ -1970,7 +1972,8 @@ struct DeviceIndex {
                 a.thr_init = nullptr;
                 sp.maxima = (float *)ws_seedkeys.p;
                 if (terms == 3) scanh_kernel<3, true><<<grid, blk, lds, st>>>(a, sp);
-                else if (halfq) scanh_kernel<1, true, true><<<grid, blk, lds, st>>>(a, sp);
+                else if (qt_act == 4) scanh_kernel<1, true, 4><<<grid, blk, lds, st>>>(a, sp);
+                else if (qt_act == 8) scanh_kernel<1, true, 8><<<grid, blk, lds, st>>>(a, sp);
                 else scanh_kernel<1, true><<<grid, blk, lds, st>>>(a, sp);
                 HAC_HIP(hipGetLastError());
                 kth_select_kernel<<<dim3((unsigned)n), dim3(256), 0, st>>>((const float *)ws_seedkeys.p, S, K2, (float *)ws_thr.p);
@@ -1990,7 +1993,8 @@ struct DeviceIndex {
                 a.g_first = bounds[ps];
                 a.n_items = bounds[ps + 1] - bounds[ps];
                 if (terms == 3) scanh_kernel<3, false><<<grid, blk, lds, st>>>(a, sp);
-                else if (halfq) scanh_kernel<1, false, true><<<grid, blk, lds, st>>>(a, sp);
+                else if (qt_act == 4) scanh_kernel<1, false, 4><<<grid, blk, lds, st>>>(a, sp);
+                else if (qt_act == 8) scanh_kernel<1, false, 8><<<grid, blk, lds, st>>>(a, sp);
                 else scanh_kernel<1, false><<<grid, blk, lds, st>>>(a, sp);
                 HAC_HIP(hipGetLastError());
                 if (ps + 1 < n_pass) {   // refresh: ws_thr[q] = max(ws_thr[q], K2-th best s~ so far)
@@ -2002,7 +2006,7 @@ struct DeviceIndex {
             }
             a.g_first = 0;
             passes_last = n_pass;
-            halfq_last = halfq;
+            qt_act_last = qt_act;
             if (profiling) {
                 HAC_HIP(hipEventRecord(ev_pool[ev_used].second, st));
                 ++ev_used;
@@ -2056,7 +2060,7 @@ struct DeviceIndex {
             HAC_HIP(hipGetLastError());
             ++split_searches;
             snprintf(plan_head, sizeof plan_head, "split: scanh_kernel<%d> grid=(%ld,%d) NQ=%d K2=%d chunks=%d lds=%zu seed=%d passes=%d rescore=%s%s", terms, P_last,
-                     n_qtiles_last, SH_NQ, K2, n_chunks, lds, seeded, passes_last, rescore_from(), halfq_last ? " tiles=half" : "");
+                     n_qtiles_last, SH_NQ, K2, n_chunks, lds, seeded, passes_last, rescore_from(), qt_act_last == 8 ? " tiles=half" : qt_act_last == 4 ? " tiles=quarter" : "");
             snprintf(last_plan, sizeof last_plan, "%s fallback=device-side/%lld", plan_head, (long long)nq);
             const int slot = plan_slot();
             HAC_HIP(hipMemcpyAsync(h_plan + 2 * slot, ws_stat.p, 8, hipMemcpyDeviceToHost, st));
@@ -2074,7 +2078,7 @@ struct DeviceIndex {
         if (level == 0) ++split_searches;
         char plan_here[sizeof last_plan];
         snprintf(plan_here, sizeof plan_here, "split: scanh_kernel<%d> grid=(%ld,%d) NQ=%d K2=%d chunks=%d lds=%zu seed=%d passes=%d rescore=%s%s fallback=%u/%lld err/bound=%.3g",
-                 terms, P_last, n_qtiles_last, SH_NQ, K2, n_chunks, lds, seeded, passes_last, rescore_from(), halfq_last ? " tiles=half" : "", nfail, (long long)nq, (double)maxratio);
+                 terms, P_last, n_qtiles_last, SH_NQ, K2, n_chunks, lds, seeded, passes_last, rescore_from(), qt_act_last == 8 ? " tiles=half" : qt_act_last == 4 ? " tiles=quarter" : "", nfail, (long long)nq, (double)maxratio);
         std::memcpy(last_plan, plan_here, sizeof last_plan);
         plan_text_slot = -1;
         if (nfail == 0) return HAC_OK;

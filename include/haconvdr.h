@@ -146,8 +146,8 @@ int hac_index_last_status(hac_index *idx);
  * far between them; auto: 3 from 1.6M rows, 4 from 8.4M), "scan_pass_cuts" = "auto" | "a,b" (where the first two passes end, in
  * thousandths of the rows; auto: the first after ~6k 64-row groups, the others in geometric progression towards the corpus), "debug_max_pass" = integer >= 0 (tests: the pass bound of the
  * candidate loops; 0 = the bound no legal input reaches),
- * "scan_halfq" = "1" (default) | "0" (development: a prefilter search of one tile with <= 128 queries runs the instantiation
- * that leaves out the empty query tiles' matrix work -- "tiles=half" in the plan text; "0" pins the full-tile form; same bits),
+ * "scan_halfq" = "1" (default) | "0" (development: a prefilter search of one tile with <= 128 / <= 64 queries runs an instantiation
+ * that leaves out the empty query tiles' matrix work -- "tiles=half" / "tiles=quarter" in the plan text; "0" pins the full-tile form; same bits),
  * "fp16_image" = "lazy" (default) | "eager": when the fp16 image of the rows (what the prefilter streams) is made: by the first
  * search that wants it, or by add() while it tiles the rows of a new segment (a resident index that will serve few queries per call
  * is then fast from its first search; best effort, +50 % of the corpus in HBM either way),

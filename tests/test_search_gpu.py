@@ -1046,7 +1046,7 @@ def test_auto_takes_the_fp16_image_for_few_queries_once_an_index_keeps_being_sea
     from haconvdr_amd.index import FlatIPIndex
     g = torch.Generator(device="cuda").manual_seed(0x5EA)
     x = torch.randn((800_000, 768), generator=g, device="cuda")
-    q = torch.randn((40, 768), generator=g, device="cuda")
+    q = torch.randn((130, 768), generator=g, device="cuda")
     idx = FlatIPIndex(768)
     idx.add_tensor(x[:760_000])
     ex = FlatIPIndex(768)
@@ -1074,12 +1074,18 @@ def test_auto_takes_the_fp16_image_for_few_queries_once_an_index_keeps_being_sea
         torch.cuda.synchronize()
         assert idx.last_plan().startswith("split:" if n >= 3 else "scan16"), (n, idx.last_plan())
         assert torch.equal(D, D0) and torch.equal(I, I0)
-    assert "tiles=half" in idx.last_plan(), idx.last_plan()        # <= 128 queries: the instantiation without the empty query tiles' matrix work
+    assert "tiles=quarter" in idx.last_plan(), idx.last_plan()     # <= 64 queries: the instantiation without the empty query tiles' matrix work
     idx.set_option("scan_halfq", "0")                              # ... and the full-tile form gives the same bits
     D, I = idx.search_tensor(q[:8], 100)
-    assert "tiles=half" not in idx.last_plan() and idx.last_plan().startswith("split:"), idx.last_plan()
+    assert "tiles=" not in idx.last_plan() and idx.last_plan().startswith("split:"), idx.last_plan()
     assert torch.equal(D, D0) and torch.equal(I, I0)
+    Df, If = idx.search_tensor(q, 100)                             # 130 queries: the general form whatever the option says
+    assert "tiles=" not in idx.last_plan() and idx.last_plan().startswith("split:"), idx.last_plan()
     idx.set_option("scan_halfq", "1")
+    for nq_, form in ((64, "tiles=quarter"), (65, "tiles=half"), (128, "tiles=half"), (129, None)):
+        D, I = idx.search_tensor(q[:nq_], 100)
+        assert (form in idx.last_plan()) if form else ("tiles=" not in idx.last_plan()), (nq_, idx.last_plan())
+        assert torch.equal(D, Df[:nq_]) and torch.equal(I, If[:nq_])
     D, I = idx.search_tensor(q[:1], 10)                            # the image is there: one query takes it too
     assert idx.last_plan().startswith("split:"), idx.last_plan()
     D1, I1 = ex.search_tensor(q[:1], 10)
