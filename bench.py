@@ -345,7 +345,7 @@ def main():
                 return dict(v, source=f"profiles/{prof['tag']}_sq.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ... GRBM_GUI_ACTIVE pass of this bench)")
         return None
     if world == 1 and rows == CFG3_ROWS:
-        search_roof["mfma_util"] = mfma_util("scanh_kernel<1, false>")
+        search_roof["mfma_util"] = mfma_util("scanh_kernel<1, false, 16>")
 
     T_tok = nq_loc * Lq                                                   # padded tokens a rank encodes per step
     enc_flops = nq_loc * 12.0 * (14155776.0 * Lq + 4.0 * Lq * Lq * 768.0) + nq_loc * 2.0 * 768 * 768

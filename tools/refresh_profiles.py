@@ -33,7 +33,7 @@ def rows_of(js, needle):
     return [c for c in js.get("counters", []) if needle in c["kernel"]]
 
 
-def per_search_counter(raw_dir, counter, kernel_needle="scanh_kernel<1, false>", end_needle="rescore_kernel"):
+def per_search_counter(raw_dir, counter, kernel_needle="scanh_kernel<1, false, 16>", end_needle="rescore_kernel"):
     """Sum of `counter` over the launches of the prefilter's main scan, search by search (a search's scan is up to three launches over
     consecutive row ranges; the rescore_kernel launch behind them closes the search).  Read from the raw counter CSVs in dispatch order."""
     rows = []
@@ -115,12 +115,12 @@ def main():
         t = {"read": int(sum(reads) / len(reads)), "write": int(sum(writes) / len(writes))}
         t["total"] = t["read"] + t["write"]
         out["search_hbm_bytes_per_launch"] = t["total"]
-        out["search"] = dict(t, per="search (all main-pass launches of scanh_kernel<1, false>)", launches_per_search=fs[0]["launches"],
+        out["search"] = dict(t, per="search (all main-pass launches of scanh_kernel<1, false, 16>)", launches_per_search=fs[0]["launches"],
                              read_per_search=[int(x) for x in reads], fp16_image_bytes=int(image),
                              read_over_image=[round(x / image, 4) for x in reads])
         if max(reads) > 1.15 * image:
             json.dump(out, open(pre + "pmc_traffic.json", "w"), indent=1)
-            sys.exit(f"scanh_kernel<1, false> fetched {max(reads) / image:.3f} x the fp16 image in one of {len(reads)} searches (limit 1.15): "
+            sys.exit(f"scanh_kernel<1, false, 16> fetched {max(reads) / image:.3f} x the fp16 image in one of {len(reads)} searches (limit 1.15): "
                      "the query tiles of a row range no longer share their rows in the L2")
     for name, needle in (("qkv", "gemm8_kernel<0,"), ("out_proj", "gemm8_kernel<2, false>"), ("ffn_down", "gemm8_kernel<2, true>"),
                          ("attention", "attention_stream_kernel<16>"),
