@@ -63,9 +63,10 @@ def _declare(L):
     L.hac_encoder_profile_drain.argtypes = [vp, c_f32p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
     L.hac_encoder_profile_drain_class.argtypes = [vp, ctypes.c_int, c_f32p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
     L.hac_encoder_last_clock.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    L.hac_encoder_attention_redo.argtypes = [vp, ctypes.POINTER(ctypes.c_longlong)]
     for name in ("hac_encoder_create", "hac_encoder_set_weight", "hac_encoder_finalize", "hac_encoder_forward",
                  "hac_encoder_forward_device", "hac_encoder_set_option", "hac_encoder_set_profiling", "hac_encoder_profile_drain",
-                 "hac_encoder_profile_drain_class", "hac_encoder_last_clock"):
+                 "hac_encoder_profile_drain_class", "hac_encoder_last_clock", "hac_encoder_attention_redo"):
         getattr(L, name).restype = ctypes.c_int
     for name in ("hac_index_create", "hac_index_add", "hac_index_add_device", "hac_index_search",
                  "hac_index_search_device", "hac_index_search_keys_device", "hac_index_reset",
@@ -82,7 +83,7 @@ EXPORTED_SYMBOLS = (
     "hac_index_last_status", "hac_merge_keys_device", "hac_keys_to_results_device",
     "hac_encoder_create", "hac_encoder_destroy", "hac_encoder_set_weight", "hac_encoder_finalize", "hac_encoder_forward",
     "hac_encoder_forward_device", "hac_encoder_set_option", "hac_encoder_last_plan", "hac_encoder_set_profiling", "hac_encoder_profile_drain",
-    "hac_encoder_profile_drain_class", "hac_encoder_last_clock",
+    "hac_encoder_profile_drain_class", "hac_encoder_last_clock", "hac_encoder_attention_redo",
 )
 
 

@@ -63,6 +63,7 @@ struct SeqInfo {
     int *nb;      // [1] number of sequences (device copy; row count of the CLS-only tail)
     int *order;   // [B] the attention kernels' work list: sequences of 257+ rows, longest first, then the others, longest first
     int *ncls;    // [2] how many of each (empty sequences are in neither)
+    int *desc;    // [B][4] (16-byte aligned) the work list's entries in full: (len, len32, first row, sequence) -- one scalar load per item (attn_pipe.inc)
 };
 
 // one workgroup per sequence: len = sum(mask), prefix check, HF position ids
@@ -165,7 +166,11 @@ __global__ __launch_bounds__(256) void attn_order_kernel(SeqInfo s, int B) {
     __syncthreads();
     for (int b = tid; b < B; b += 256) {
         const int k = min(s.len32[b] >> 5, 16);
-        if (k > 0) s.order[start[k] + atomicAdd(&hist[k], 1)] = b;
+        if (k > 0) {
+            const int slot = start[k] + atomicAdd(&hist[k], 1);
+            s.order[slot] = b;
+            *reinterpret_cast<int4 *>(s.desc + 4 * slot) = make_int4(s.lens[b], s.len32[b], s.off[b], b);
+        }
     }
 }
 
@@ -685,7 +690,13 @@ struct AttnArgs {
     int cls_only;        // last layer: only the query block holding <s> is needed (models.py:56 takes [:,0])
     int qsplit;          // streaming kernel, small batches: an item's query rows are dealt to this many workgroups (1, 2, 4, 8 or 16), see there
     int one_class;       // streaming kernel, small batches: the 16-wave instantiation takes the short sequences too (one launch per layer)
+    // the two-blocks-per-wave kernel (attn_pipe.inc) computes every item with the reference at 0 and flags those that need it moved:
+    int *redo_flags;     // [items of both classes] 1: compute again (set by attention_pipe_kernel, taken and cleared by the fix-up pass)
+    int *redo_count;     // [1] how many were flagged in this layer (zeroed per forward)
+    int fixup;           // attention_stream_kernel: take only flagged items
 };
+// How far (log2 domain) a score may lie from a row's reference before the reference is moved: the streaming kernels' shared rule.
+constexpr float ATT_TAU = 64.0f;
 
 // The two-pass attention kernel of round 1, kept behind hac_encoder_set_option("attn", "twopass") as the tests' cross-check of
 // the streaming kernel below (exact row maxima first, one workgroup per item).
@@ -882,7 +893,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES * U == 8 ? 2 : 1) void attention_
 // the (sequence, head) items, two chunks ahead of the arithmetic, one K piece and one V piece per wave and chunk; the next
 // item's Q rows are staged through LDS the same way.  K passes through once: the softmax is the online form (running
 // reference m per query row, P = 2^(s - m) with the accumulator started at -m; m is only raised, exactly, when a block's
-// maximum exceeds it by more than TAU = 40 (in the log2 domain) -- then l and O are rescaled -- so P <= 2^40 and the common step has
+// maximum exceeds it by more than TAU = ATT_TAU = 64 (in the log2 domain) -- then l and O are rescaled -- so P <= 2^64 and the common step has
 // no rescale).
 //   WAVES = 16: sequences of 257..512 rows, chunks of 128 keys, 160 KiB of LDS, one workgroup per CU;
 //   WAVES = 8 : up to 256 rows, chunks of 64 keys, 80 KiB, two workgroups per CU.
@@ -905,10 +916,10 @@ __global__ __launch_bounds__(WAVES * 64, 4) void attention_stream_kernel(AttnArg
     constexpr int STAGE = CHUNK * 256;           // bytes: K rows (CHUNK x 128) | V pieces (CHUNK x 128)
     constexpr int QBYTES = WAVES * 32 * 128;     // the item's Q rows
     // How far a score may exceed the reference before the reference is moved.  P = 2^(s - m) <= 2^TAU is held in bf16 (8-bit
-    // exponent) and summed in fp32: 512 keys x 2^40 x |v| stays far inside the range, the relative precision of P does not depend
+    // exponent) and summed in fp32: 512 keys x 2^64 x |v| stays far inside the range, the relative precision of P does not depend
     // on its scale, and a row's first block always contains P = 1 -- so a generous margin costs nothing and makes the rescale a
     // rare event on any realistic logits (with 8 it ran on most steps once the logits' standard deviation reached ~5).
-    constexpr float TAU = 40.0f;
+    constexpr float TAU = ATT_TAU;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *const ring = smem + QBYTES;
     const int lane = threadIdx.x & 63;
@@ -932,7 +943,15 @@ __global__ __launch_bounds__(WAVES * 64, 4) void attention_stream_kernel(AttnArg
     // faster (the step is bound by the SIMD's VALU issue), more CUs work: 4 x 512 tokens 19 -> ~8 us per layer.  Same arithmetic per row.
     const int QS = a.cls_only ? 1 : min(a.qsplit, WAVES);
     const int n_items = (WAVES == 16 ? n_long : sload(a.s.ncls, 1)) * NH * QS;
-    auto next_item = [&](int t) { return t + G; };
+    // Fix-up mode (behind attention_pipe_kernel, which computes every item with the reference at 0 and flags the ones whose
+    // reference has to move): only flagged items are taken; each is visited by exactly one workgroup, which clears its flag.
+    if (a.fixup && sload(a.redo_count, 0) == 0) return;
+    auto next_item = [&](int t) {
+        t += G;
+        if (a.fixup)
+            while (t < n_items && sload(a.redo_flags, list0 * NH + t) == 0) t += G;
+        return t;
+    };
     struct Item { int len, len32, head, nch, q0; size_t base; };
     auto describe = [&](int t) {
         const int part = t % QS, th = t / QS;
@@ -1043,10 +1062,13 @@ __global__ __launch_bounds__(WAVES * 64, 4) void attention_stream_kernel(AttnArg
 #pragma unroll
             for (int e = 0; e < 16; ++e)
                 if (!MASKED || kb * 32 + key_of(e) < len) mloc = fmaxf(mloc, s[e]);
+            // (round 6) the reference starts at 0 and moves only when it has to: a block's maximum more than TAU above it or -- first
+            // block -- more than TAU below.  Rows whose scores stay within +-ATT_TAU keep m = 0, which the two-blocks-per-wave
+            // kernel (attn_pipe.inc) exploits; the rule is shared so that the two kernels stay bit-identical.
             const bool first = kb == 0;
-            if (first || __builtin_amdgcn_ballot_w64(mloc > TAU) != 0) {   // (wave-uniform) move the reference, exactly
+            if (__builtin_amdgcn_ballot_w64(mloc > TAU || (first && mloc < -TAU)) != 0) {   // (wave-uniform) move the reference, exactly
                 const float mrow = fmaxf(mloc, __shfl_xor(mloc, 32));       // the query row's maximum over the block
-                const float delta = first ? mrow : (mrow > TAU ? mrow : 0.f);
+                const float delta = (mrow > TAU || (first && mrow < -TAU)) ? mrow : 0.f;
                 const float sc = first ? 1.f : __builtin_amdgcn_exp2f(-delta);   // (first block: l and O are still zero)
                 m_ref += delta;
 #pragma unroll
@@ -1154,12 +1176,18 @@ __global__ __launch_bounds__(WAVES * 64, 4) void attention_stream_kernel(AttnArg
         }
         ATTS_T(20);
         stored = active;
+        if (a.fixup && w == 0) {       // (rare path: the drained queue makes the counted waits that follow hold trivially)
+            if (lane == 0) a.redo_flags[list0 * NH + t] = 0;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         if (!has_next) break;
         cur = nxt;
         t = tn;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stream's last read-ahead writes LDS: it must land before the workgroup ends
 }
+
+#include "attn_pipe.inc"
 
 // Last layer: everything after attention is only needed for the <s> row of each sequence
 // (masked_mean_or_first with use_mean=False, src/models.py:52-56): gather those B rows into compact
@@ -1339,6 +1367,8 @@ struct hac_encoder {
     GrowBuf ws_yb, ws_part, ws_idstats;   // gemm8 path: bf16 copy of the attention-block rows, row-sum partials, (0, 1) statistics
     size_t idstats_rows = 0;
     int attn_mode = 0;                    // 0: streaming single-pass attention; 1: two-pass kernels (cross-check)
+    int attn_pipe = -1;                   // streaming attention of whole items (no query split, not the <s>-only layer): two query blocks per wave, woven (attn_pipe.inc); 0: the one-block kernel everywhere
+    int plan_attn_pipe = 0;               // what the most recent forward's layers used
     int gemm_mode = -1;                   // -1: by size, 0: classic kernels only, 1: gemm8 whenever the batch has a full tile (tests)
     // gemm8 loop form per class (bit 0 QKV, 1 out-proj, 2 FFN-up, 3 FFN-down; 1 = SPLIT, 0 = round 2's loop, kept for A/B runs).
     // A/B in one process on the 1000 x 512 forward (tools/ab_encoder.py), two boxes: SPLIT -1 .. -3.4 % on FFN-down (K = 3072),
@@ -1382,12 +1412,14 @@ struct hac_encoder {
         const char *gemm = "none";
         long rows = 0;
         int ks_out = 1, ks_down = 1;      // the plan of the captured forward (a replay runs no host-side planning)
+        int attn_pipe = 0;
     };
     std::map<uint64_t, GraphEntry> graphs;
     hipEvent_t graph_done = nullptr;      // recorded behind every replay on the caller's stream: an exec is destroyed only after it
     bool graph_done_armed = false;
     GrowBuf ws_gids, ws_gmask, ws_gout;
     GrowBuf ws_identgb;                   // [2][768]: gamma = 1, beta = 0
+    GrowBuf ws_redo;                      // [16] per-layer counts | [B * 12] item flags of the attention fix-up pass (attn_pipe.inc)
     GrowBuf ws_clk;                       // [4] u64: hac_encoder_last_clock
     bool clk_valid = false;
 };
@@ -1433,9 +1465,11 @@ int prof_end(hac_encoder *e, int pool, hipStream_t st) {
 
 // carve the sequence bookkeeping of a (sub-)batch out of ws_seq
 int seq_layout(hac_encoder *e, int B, int L, SeqInfo &s) {
-    const size_t seq_ints = (size_t)5 * B + 6 + (size_t)B * L;
+    const size_t seq_ints = (size_t)4 * B + (size_t)5 * B + 8 + (size_t)B * L;
     HAC_TRY(e->ws_seq.reserve(seq_ints * 4));
     int *p = (int *)e->ws_seq.p;
+    s.desc = p;                 // 4 B entries, 16-byte aligned (hipMalloc's alignment)
+    p += (size_t)4 * B;
     s.lens = p;
     s.len32 = p + B;
     s.off = p + 2 * B;          // B+1 entries
@@ -1632,12 +1666,31 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
         while (e->attn_qsplit != 0 && att_qs < 16 && (long)B * NH * att_qs * 2 <= e->n_cu) att_qs *= 2;
         if (e->attn_qs_pin > 0) att_qs = e->attn_qs_pin;   // development (tools/ks_sweep.py attn)
         const bool att_one = att_qs > 1 && L32 > 256;   // few sequences: one launch (an empty second one is 5 us of a ~100-us layer)
-        AttnArgs a{q, k, vt, ctx, s, last ? 1 : 0, att_qs, att_one ? 1 : 0};
+        AttnArgs a{q, k, vt, ctx, s, last ? 1 : 0, att_qs, att_one ? 1 : 0, nullptr, nullptr, 0};
+        if (li == 0) e->plan_attn_pipe = 0;
+        const bool att_pipe = e->attn_mode == 0 && e->attn_pipe != 0 && att_qs == 1 && !last;
+        if (att_pipe) {
+            if (!e->plan_attn_pipe) {      // the forward's first woven layer: workspace, per-layer counts to zero (the flags are zero whenever no pass is pending)
+                HAC_TRY(e->ws_redo.reserve(((size_t)B * NH + 16) * 4));
+                HAC_HIP(hipMemsetAsync(e->ws_redo.p, 0, 64, st));
+            }
+            a.redo_count = (int *)e->ws_redo.p + (li & 15);
+            a.redo_flags = (int *)e->ws_redo.p + 16;
+        }
         // sequences of <= 256 rows: 4-wave workgroups; longer ones: 8-wave workgroups (each skips the other's)
         HAC_TRY(prof_begin(e, 1 + HAC_ENC_CLASS_ATTN, st));
         if (e->attn_mode == 0) {           // persistent streaming kernels, one launch per length class
-            if (L32 > 256) attention_stream_kernel<16><<<dim3(e->n_cu), dim3(1024), 163840, st>>>(a);
-            if (!att_one) attention_stream_kernel<8><<<dim3(2 * e->n_cu), dim3(512), 81920, st>>>(a);
+            if (att_pipe) {   // whole items: the woven two-blocks-per-wave form, then the items it flagged through the one-block kernels (bit-identical results)
+                if (L32 > 256) attention_pipe_kernel<8><<<dim3(e->n_cu), dim3(512), 163840, st>>>(a);
+                attention_pipe_kernel<4><<<dim3(2 * e->n_cu), dim3(256), 81920, st>>>(a);
+                a.fixup = 1;
+                if (L32 > 256) attention_stream_kernel<16><<<dim3(e->n_cu), dim3(1024), 163840, st>>>(a);
+                attention_stream_kernel<8><<<dim3(2 * e->n_cu), dim3(512), 81920, st>>>(a);
+                e->plan_attn_pipe = 1;
+            } else {
+                if (L32 > 256) attention_stream_kernel<16><<<dim3(e->n_cu), dim3(1024), 163840, st>>>(a);
+                if (!att_one) attention_stream_kernel<8><<<dim3(2 * e->n_cu), dim3(512), 81920, st>>>(a);
+            }
         } else {                           // two-pass kernels, one workgroup per (sequence, head): kept as a cross-check
             attention_kernel<8, 1><<<dim3(NH, B), dim3(512), (size_t)(L32 < 256 ? L32 : 256) * 256, st>>>(a);
             if (L32 > 256) attention_kernel<16, 1><<<dim3(NH, B), dim3(1024), (size_t)L32 * 256, st>>>(a);
@@ -1742,7 +1795,7 @@ constexpr long GRAPH_MAX_ROWS = 16384;   // beyond this a forward is millisecond
 uint64_t ws_signature(const hac_encoder *e) {
     uint64_t h = 1469598103934665603ull;
     for (const GrowBuf *b : {&e->ws_x, &e->ws_xb, &e->ws_q, &e->ws_k, &e->ws_vt, &e->ws_ctx, &e->ws_y, &e->ws_h, &e->ws_seq, &e->ws_cls, &e->ws_stats,
-                             &e->ws_yb, &e->ws_part, &e->ws_idstats, &e->ws_gids, &e->ws_gmask, &e->ws_gout, &e->ws_ksplit})
+                             &e->ws_yb, &e->ws_part, &e->ws_idstats, &e->ws_gids, &e->ws_gmask, &e->ws_gout, &e->ws_ksplit, &e->ws_redo})
         h = (h ^ (uint64_t)(uintptr_t)b->p) * 1099511628211ull;
     return h;
 }
@@ -1778,7 +1831,7 @@ int forward_graph(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, f
     HAC_TRY(e->ws_gout.reserve(n_out));
     const uint64_t key = ((uint64_t)B << 40) | ((uint64_t)L << 24) | ((uint64_t)sizeof(IT) << 16) | ((uint64_t)(e->attn_mode & 1) << 8) |
                          ((uint64_t)((e->gemm_mode + 1) & 3) << 4) | (uint64_t)(e->g8_split & 15) | ((uint64_t)(e->ksplit_mode & 1) << 12) |
-                         ((uint64_t)(e->attn_qsplit & 1) << 13) | ((uint64_t)(e->g8_stagger & 1) << 14);
+                         ((uint64_t)(e->attn_qsplit & 1) << 13) | ((uint64_t)(e->g8_stagger & 1) << 14) | ((uint64_t)(e->attn_pipe & 1) << 15);
     // (a caller that pads every batch to its own longest sequence can show hundreds of shapes: the cache is bounded, and starting
     // over costs each live shape one plain forward and one capture)
     if (e->graphs.size() >= GRAPH_MAX_SHAPES && e->graphs.find(key) == e->graphs.end()) drop_graphs(e);
@@ -1798,6 +1851,7 @@ int forward_graph(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, f
         ge.rows = e->plan_rows;
         ge.ks_out = e->plan_ks_out;
         ge.ks_down = e->plan_ks_down;
+        ge.attn_pipe = e->plan_attn_pipe;
         e->plan_sub_batches = 1;
         e->plan_graph = "eager-first";
     } else {
@@ -1822,6 +1876,8 @@ int forward_graph(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, f
             ge.rows = e->plan_rows;
             ge.ks_out = e->plan_ks_out;
             ge.ks_down = e->plan_ks_down;
+            ge.attn_pipe = e->plan_attn_pipe;
+        ge.attn_pipe = e->plan_attn_pipe;
         }
         HAC_HIP(hipGraphLaunch(ge.exec, st));
         if (!e->graph_done) HAC_HIP(hipEventCreateWithFlags(&e->graph_done, hipEventDisableTiming));
@@ -1831,6 +1887,7 @@ int forward_graph(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, f
         e->plan_rows = ge.rows;
         e->plan_ks_out = ge.ks_out;
         e->plan_ks_down = ge.ks_down;
+        e->plan_attn_pipe = ge.attn_pipe;
         e->plan_graph = "replay";
     }
     HAC_HIP(hipMemcpyAsync(out_dev, gout, n_out, hipMemcpyDeviceToDevice, st));
@@ -1912,6 +1969,8 @@ int hac_encoder_create(const hac_encoder_config *cfg, int device, hac_encoder **
     (void)hipFuncSetAttribute((const void *)attention_kernel<16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     (void)hipFuncSetAttribute((const void *)attention_stream_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
     (void)hipFuncSetAttribute((const void *)attention_stream_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    (void)hipFuncSetAttribute((const void *)attention_pipe_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
+    (void)hipFuncSetAttribute((const void *)attention_pipe_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
     (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_QKV, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
     (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_RESID, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
     (void)hipFuncSetAttribute((const void *)gemm_bf16_nt_kernel<EPI_GELU, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
@@ -1957,7 +2016,7 @@ void hac_encoder_destroy(hac_encoder *e) {
     drop_graphs(e);
     if (e->graph_done) (void)hipEventDestroy(e->graph_done);
     for (GrowBuf *b : {&e->ws_x, &e->ws_xb, &e->ws_q, &e->ws_k, &e->ws_vt, &e->ws_ctx, &e->ws_y, &e->ws_h, &e->ws_seq, &e->ws_ids, &e->ws_mask, &e->ws_out, &e->ws_cls, &e->ws_stats, &e->ws_yb, &e->ws_part, &e->ws_idstats,
-                       &e->ws_gids, &e->ws_gmask, &e->ws_gout, &e->ws_ksplit, &e->ws_identgb, &e->ws_clk})
+                       &e->ws_gids, &e->ws_gmask, &e->ws_gout, &e->ws_ksplit, &e->ws_identgb, &e->ws_clk, &e->ws_redo})
         b->release();
     if (e->h_pin) (void)hipHostFree(e->h_pin);
     if (e->h_len) (void)hipHostFree(e->h_len);
@@ -2121,6 +2180,9 @@ int hac_encoder_set_option(hac_encoder *e, const char *name, const char *value) 
     } else if (n == "attn") {
         if (v != "stream" && v != "twopass") return fail(HAC_ERR_INVALID, "encoder option attn = '%s': stream | twopass", value);
         e->attn_mode = v == "twopass" ? 1 : 0;
+    } else if (n == "attn_pipe") {
+        if (v != "auto" && v != "off") return fail(HAC_ERR_INVALID, "encoder option attn_pipe = '%s': auto | off", value);
+        e->attn_pipe = v == "off" ? 0 : -1;
     } else if (n == "g8_split") {
         char *end = nullptr;
         const long t = strtol(value, &end, 10);
@@ -2161,8 +2223,8 @@ int hac_encoder_set_option(hac_encoder *e, const char *name, const char *value) 
 
 const char *hac_encoder_last_plan(hac_encoder *e) {
     if (!e) return "none";
-    snprintf(e->last_plan, sizeof e->last_plan, "gemm=%s attn=%s sub_batches=%d rows=%ld graph=%s ksplit=%d/%d", e->plan_gemm, e->attn_mode ? "twopass" : "stream",
-             e->plan_sub_batches, e->plan_rows, e->plan_graph, e->plan_ks_out, e->plan_ks_down);
+    snprintf(e->last_plan, sizeof e->last_plan, "gemm=%s attn=%s sub_batches=%d rows=%ld graph=%s ksplit=%d/%d attn_form=%s", e->plan_gemm, e->attn_mode ? "twopass" : "stream",
+             e->plan_sub_batches, e->plan_rows, e->plan_graph, e->plan_ks_out, e->plan_ks_down, e->attn_mode ? "twopass" : (e->plan_attn_pipe ? "woven" : "single"));
     return e->last_plan;
 }
 
@@ -2202,6 +2264,19 @@ int hac_encoder_last_clock(hac_encoder *e, uint64_t out[2]) {
         out[0] = h[2] - h[0];
         out[1] = h[3] - h[1];
     }
+    return HAC_OK;
+}
+
+int hac_encoder_attention_redo(hac_encoder *e, long long *items_out) {
+    if (!e || !items_out) return fail(HAC_ERR_INVALID, "hac_encoder_attention_redo: null argument");
+    *items_out = 0;
+    if (!e->ws_redo.p) return HAC_OK;
+    DeviceGuard g(e->device);
+    int h[16] = {0};
+    HAC_HIP(hipDeviceSynchronize());
+    HAC_HIP(hipMemcpy(h, e->ws_redo.p, sizeof h, hipMemcpyDeviceToHost));
+    // (a wave that finds a row outside the window counts its item once; several waves of one item may: an upper bound of the items, 0 iff none)
+    for (int i = 0; i < 16; ++i) *items_out += h[i];
     return HAC_OK;
 }
 

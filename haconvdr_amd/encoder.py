@@ -160,6 +160,13 @@ class ANCEEncoder:
             return None
         return 100.0 * int(out[0]) / int(out[1]), int(out[1]) / 100e6
 
+    def attention_redo(self):
+        """How often the woven attention kernel handed an item to its fix-up pass in the most recent forward (upper bound of
+        the items, 0 iff none; hac_encoder_attention_redo).  Test aid; waits for the device."""
+        n = ctypes.c_longlong()
+        _lib.check(_lib.lib().hac_encoder_attention_redo(self._h, ctypes.byref(n)))
+        return int(n.value)
+
     def profile_drain_class(self, name, cap=16384):
         """Durations (ms, launch order) of the launches of one kernel class since the last drain."""
         buf = (ctypes.c_float * cap)()

@@ -242,14 +242,16 @@ int hac_encoder_forward_device(hac_encoder *enc, const void *ids_dev, const void
  * classes -- bit 0 QKV, 1 out-proj, 2 FFN-up, 3 FFN-down -- run the operand-split loop of the large-batch GEMM, default
  * 15; 0 = round 2's loop: same results bit for bit); "attn_qsplit" = "auto" (default) | "off" (with few sequences the streaming
  * attention kernel deals the query rows of a (sequence, head) item to 2..16 workgroups and runs both length classes in one launch;
- * same bits); "g8_stagger" = "auto" (default) | "off" (the workgroups of the large-batch
+ * same bits); "attn_pipe" = "auto" (default) | "off" (whole (sequence, head) items -- no query split, not the <s>-only last layer -- go through the
+ * kernel with two query blocks per wave, the softmax of one woven into the MFMAs of the other, followed by a fix-up pass of the one-block kernel over the
+ * items whose softmax reference has to move; "off": the one-block kernel everywhere; same bits); "g8_stagger" = "auto" (default) | "off" (the workgroups of the large-batch
  * QKV and out-projection GEMMs start in four phases, one per pair of XCDs, so that their epilogues do not reach HBM all at once;
  * timing only, same bits).  Any other name or value is HAC_ERR_INVALID (never a
  * silent default).  HAC_ENC_GEMM gives the default of "gemm" and is read once, in hac_encoder_create.
  * "auto" decides ONCE per forward call, from the rows of the whole batch: every sub-batch of a call runs the same
  * GEMM family and tile size, so a sequence's embedding does not depend on the sub-batch it fell into. */
 int hac_encoder_set_option(hac_encoder *enc, const char *name, const char *value);
-/* What the most recent forward ran: "gemm=gemm8|classic256|classic128 attn=stream|twopass sub_batches=N rows=R graph=off|eager-first|replay ksplit=S_out/S_down"
+/* What the most recent forward ran: "gemm=gemm8|classic256|classic128 attn=stream|twopass sub_batches=N rows=R graph=off|eager-first|replay ksplit=S_out/S_down attn_form=woven|single|twopass"
  * (tests and bench.py assert the kernel family they mean to check).  The GEMM family and, with the classic kernels, the tile
  * size are chosen once per call, from the rows of the whole batch: every sub-batch runs the same kernels. */
 const char *hac_encoder_last_plan(hac_encoder *enc);
@@ -278,6 +280,12 @@ int hac_encoder_profile_drain_class(hac_encoder *enc, int cls, float *ms_out, in
  * stream of that launch.  clock = out[0] / out[1] x 100 MHz -- the figure fractions of a peak are normalised by, because boxes
  * of one pool hold different clocks under the same load.  Costs the kernel nothing (two scalar reads, four stores). */
 int hac_encoder_last_clock(hac_encoder *enc, uint64_t out[2]);
+/* Test aid: how often the woven attention kernel (attn_pipe.inc) handed an item to the fix-up pass in the most recent forward
+ * (last sub-batch) -- a wave counts its item when one of its rows left the window in which a row's softmax reference stays 0
+ * (a score above 2^63 relative to 1, or a first key block wholly below 2^-64); several waves of one item may count it: an upper
+ * bound of the items, 0 iff none.  Waits for the device.  The results do not depend on it: the fix-up pass is the one-block
+ * kernel, whose outputs the woven kernel's equal bit for bit wherever it does not flag. */
+int hac_encoder_attention_redo(hac_encoder *enc, long long *items_out);
 
 #ifdef __cplusplus
 }

@@ -26,13 +26,22 @@ int main(int argc, char** argv){
   for(int i=0;i<=B;i++) off[i]=i*L;
   for(int i=0;i<B;i++) order[i]=i;
   ncls[0] = L > 256 ? B : 0; ncls[1] = L > 256 ? 0 : B;
-  SeqInfo s{}; CK(hipMalloc(&s.lens,B*4)); CK(hipMalloc(&s.len32,B*4)); CK(hipMalloc(&s.off,(B+1)*4)); CK(hipMalloc(&s.order,B*4)); CK(hipMalloc(&s.ncls,8));
+  SeqInfo s{}; CK(hipMalloc(&s.desc,(size_t)B*16));
+  { std::vector<int> d((size_t)B*4); for (int i=0;i<B;i++){ d[4*i]=L; d[4*i+1]=L; d[4*i+2]=i*L; d[4*i+3]=i; } CK(hipMemcpy(s.desc,d.data(),(size_t)B*16,hipMemcpyHostToDevice)); }
+  CK(hipMalloc(&s.lens,B*4)); CK(hipMalloc(&s.len32,B*4)); CK(hipMalloc(&s.off,(B+1)*4)); CK(hipMalloc(&s.order,B*4)); CK(hipMalloc(&s.ncls,8));
   CK(hipMemcpy(s.lens,lens.data(),B*4,hipMemcpyHostToDevice)); CK(hipMemcpy(s.len32,len32.data(),B*4,hipMemcpyHostToDevice)); CK(hipMemcpy(s.off,off.data(),(B+1)*4,hipMemcpyHostToDevice));
   CK(hipMemcpy(s.order,order.data(),B*4,hipMemcpyHostToDevice)); CK(hipMemcpy(s.ncls,ncls.data(),8,hipMemcpyHostToDevice));
   AttnArgs a{}; a.q=q; a.k=k; a.v16=vt; a.ctx=ctx; a.s=s; a.cls_only=0; a.qsplit=1; a.one_class=0;
+  const int form = argc > 3 ? atoi(argv[3]) : 0;   // 0: one block per wave (attention_stream_kernel), 1: two blocks per wave, woven (attention_pipe_kernel)
+  int *redo; CK(hipMalloc(&redo, (size_t)(B * 12 + 16) * 4)); CK(hipMemset(redo, 0, (size_t)(B * 12 + 16) * 4));
+  a.redo_count = redo; a.redo_flags = redo + 16; a.fixup = 0;
+  CK(hipFuncSetAttribute((const void *)attention_pipe_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920));
+  CK(hipFuncSetAttribute((const void *)attention_pipe_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
   CK(hipFuncSetAttribute((const void *)attention_stream_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920));
   CK(hipFuncSetAttribute((const void *)attention_stream_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
-  auto launch=[&]{ if (L > 256) attention_stream_kernel<16><<<256,1024,163840>>>(a); else attention_stream_kernel<8><<<512,512,81920>>>(a); };
+  auto launch=[&]{
+    if (form == 1) { if (L > 256) attention_pipe_kernel<8><<<256,512,163840>>>(a); else attention_pipe_kernel<4><<<512,256,81920>>>(a); }
+    else { if (L > 256) attention_stream_kernel<16><<<256,1024,163840>>>(a); else attention_stream_kernel<8><<<512,512,81920>>>(a); } };
   hipEvent_t e0,e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for(int i=0;i<2;i++) launch();
   CK(hipDeviceSynchronize());
@@ -42,7 +51,21 @@ int main(int argc, char** argv){
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms,e0,e1)); ms/=it;
   double fl = 4.0*B*12*(double)L*L*64;
+  { int h[16]; CK(hipMemcpy(h, redo, 64, hipMemcpyDeviceToHost)); printf("form %d (flagged items %d) ", form, h[0] / (it + 2)); }
   printf("L=%d qscale %.2f: %.3f ms  %.0f TF (useful)  %.0f cycles@2GHz per item per CU\n", L, qs, ms, fl/ms/1e9, ms*1e-3*2e9/(B*12/(L>256?256.0:512.0)));
+#ifdef ATTP_STAMP
+  if (form == 1) { unsigned long long st[512]; CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(hac::g_attp_stamps), sizeof(st)));
+    for (int w : {0, 3, 4, 7}) { const unsigned long long *q = st + w * 64;
+      printf(" wave %d: wait+barrier %lld | to prologue %lld | first pair %lld | loop iterations [Y + X]:", w, (long long)(q[1]-q[0]), (long long)(q[2]-q[1]), (long long)(q[4]-q[2]));
+      for (int i = 1; i < 14; ++i) if (q[4+i] > q[3+i]) printf(" %lld[%lld+%lld]", (long long)(q[4+i]-q[3+i]), (long long)(q[44+i]-q[3+i]), (long long)(q[4+i]-q[44+i]));
+      printf(" | boundaries (wait+barrier):"); for (int c = 1; c < 4; ++c) printf(" %lld", (long long)(q[21+2*c]-q[20+2*c]));
+      printf(" | last PV + stores %lld | item %lld\n", (long long)(q[19]-q[18]), (long long)(q[19]-q[0])); }
+    for (int w : {0, 4}) { const unsigned long long *q = st + w * 64; const unsigned long long t0 = st[0];
+      printf(" wave %d timeline (cycles from wave 0's item start): start %lld, past first barrier %lld, prologue %lld, iterations at", w, (long long)(q[0]-t0), (long long)(q[1]-t0), (long long)(q[2]-t0));
+      for (int i = 1; i < 14; ++i) printf(" %lld", (long long)(q[3+i]-t0));
+      printf(" | boundary waits begin/end:"); for (int c = 1; c < 4; ++c) printf(" %lld-%lld", (long long)(q[20+2*c]-t0), (long long)(q[21+2*c]-t0));
+      printf(" | drain done %lld, item done %lld\n", (long long)(q[18]-t0), (long long)(q[19]-t0)); } }
+#endif
 #ifdef ATT_STAMP
   { unsigned long long st[512]; CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(hac::g_att_stamps), sizeof(st)));
     const int nch = L > 256 ? (L+127)/128 : (L+63)/64;
