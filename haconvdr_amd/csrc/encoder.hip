@@ -1668,7 +1668,10 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
         const bool att_one = att_qs > 1 && L32 > 256;   // few sequences: one launch (an empty second one is 5 us of a ~100-us layer)
         AttnArgs a{q, k, vt, ctx, s, last ? 1 : 0, att_qs, att_one ? 1 : 0, nullptr, nullptr, 0};
         if (li == 0) e->plan_attn_pipe = 0;
-        const bool att_pipe = e->attn_mode == 0 && e->attn_pipe != 0 && att_qs == 1 && !last;
+        // (measured, 512 sequences of one length: 512 rows 0.587 against 0.603 ms for the one-block kernel, 384 rows 0.413 / 0.389, 256 rows
+        // 0.215 / 0.182 -- an item's ~15 k cycles of start-up and drain weigh more the shorter it is: the woven form takes the long class of
+        // batches padded beyond 384 rows, the one-block kernel everything else; same bits either way)
+        const bool att_pipe = e->attn_mode == 0 && e->attn_pipe != 0 && att_qs == 1 && !last && (L32 > 384 || e->attn_pipe > 0);
         if (att_pipe) {
             if (!e->plan_attn_pipe) {      // the forward's first woven layer: workspace, per-layer counts to zero (the flags are zero whenever no pass is pending)
                 HAC_TRY(e->ws_redo.reserve(((size_t)B * NH + 16) * 4));
@@ -1681,11 +1684,13 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
         HAC_TRY(prof_begin(e, 1 + HAC_ENC_CLASS_ATTN, st));
         if (e->attn_mode == 0) {           // persistent streaming kernels, one launch per length class
             if (att_pipe) {   // whole items: the woven two-blocks-per-wave form, then the items it flagged through the one-block kernels (bit-identical results)
+                const bool both = e->attn_pipe > 0;   // "all" (tests): the short class through the 4-wave instantiation too
                 if (L32 > 256) attention_pipe_kernel<8><<<dim3(e->n_cu), dim3(512), 163840, st>>>(a);
-                attention_pipe_kernel<4><<<dim3(2 * e->n_cu), dim3(256), 81920, st>>>(a);
+                if (both) attention_pipe_kernel<4><<<dim3(2 * e->n_cu), dim3(256), 81920, st>>>(a);
+                else attention_stream_kernel<8><<<dim3(2 * e->n_cu), dim3(512), 81920, st>>>(a);
                 a.fixup = 1;
                 if (L32 > 256) attention_stream_kernel<16><<<dim3(e->n_cu), dim3(1024), 163840, st>>>(a);
-                attention_stream_kernel<8><<<dim3(2 * e->n_cu), dim3(512), 81920, st>>>(a);
+                if (both) attention_stream_kernel<8><<<dim3(2 * e->n_cu), dim3(512), 81920, st>>>(a);
                 e->plan_attn_pipe = 1;
             } else {
                 if (L32 > 256) attention_stream_kernel<16><<<dim3(e->n_cu), dim3(1024), 163840, st>>>(a);
@@ -1831,7 +1836,7 @@ int forward_graph(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, f
     HAC_TRY(e->ws_gout.reserve(n_out));
     const uint64_t key = ((uint64_t)B << 40) | ((uint64_t)L << 24) | ((uint64_t)sizeof(IT) << 16) | ((uint64_t)(e->attn_mode & 1) << 8) |
                          ((uint64_t)((e->gemm_mode + 1) & 3) << 4) | (uint64_t)(e->g8_split & 15) | ((uint64_t)(e->ksplit_mode & 1) << 12) |
-                         ((uint64_t)(e->attn_qsplit & 1) << 13) | ((uint64_t)(e->g8_stagger & 1) << 14) | ((uint64_t)(e->attn_pipe & 1) << 15);
+                         ((uint64_t)(e->attn_qsplit & 1) << 13) | ((uint64_t)(e->g8_stagger & 1) << 14) | ((uint64_t)((e->attn_pipe + 1) & 3) << 15);
     // (a caller that pads every batch to its own longest sequence can show hundreds of shapes: the cache is bounded, and starting
     // over costs each live shape one plain forward and one capture)
     if (e->graphs.size() >= GRAPH_MAX_SHAPES && e->graphs.find(key) == e->graphs.end()) drop_graphs(e);
@@ -2181,8 +2186,8 @@ int hac_encoder_set_option(hac_encoder *e, const char *name, const char *value) 
         if (v != "stream" && v != "twopass") return fail(HAC_ERR_INVALID, "encoder option attn = '%s': stream | twopass", value);
         e->attn_mode = v == "twopass" ? 1 : 0;
     } else if (n == "attn_pipe") {
-        if (v != "auto" && v != "off") return fail(HAC_ERR_INVALID, "encoder option attn_pipe = '%s': auto | off", value);
-        e->attn_pipe = v == "off" ? 0 : -1;
+        if (v != "auto" && v != "off" && v != "all") return fail(HAC_ERR_INVALID, "encoder option attn_pipe = '%s': auto | off | all", value);
+        e->attn_pipe = v == "off" ? 0 : (v == "all" ? 1 : -1);
     } else if (n == "g8_split") {
         char *end = nullptr;
         const long t = strtol(value, &end, 10);

@@ -988,6 +988,7 @@ struct DeviceIndex {
         bool image_eager = false;        // "fp16_image" = "eager": the fp16 image is written by add() (new segments), not by a later search
         int rescore_rows = -1;           // row-major copy for the rescoring: -1 by size (<= RESCORE_ROWS_MAX rows), 0 never, 1 whenever it can be allocated
         int debug_max_pass = 0;          // tests: pass bound of the candidate loops (0 = the kernels' own, which no legal input reaches)
+        int debug_oom = 0;               // tests: the next N allocations the index needs behave as if their first attempt had found the device full (malloc_reclaiming)
         int scan_passes = 0;             // prefilter scan: 0 by size, 1..5 pins the number of passes (threshold refreshes between them)
         int pass_cut[2] = {0, 0};        // where the passes end, in thousandths of the row groups (option "scan_pass_cuts" = "a,b"); 0 = by size
     } tune;
@@ -1080,6 +1081,11 @@ struct DeviceIndex {
         } else if (n == "rescore_rows") {
             if (!one_of({"0", "1", "auto"})) return HAC_ERR_INVALID;
             tune.rescore_rows = v == "0" ? 0 : (v == "1" ? 1 : -1);
+        } else if (n == "debug_oom") {
+            char *end = nullptr;
+            const long t = strtol(v.c_str(), &end, 10);
+            if (v.empty() || *end || t < 0 || t > 1000) return fail(HAC_ERR_INVALID, "index option debug_oom = '%s': an integer 0..1000", v.c_str());
+            tune.debug_oom = (int)t;
         } else if (n == "debug_max_pass") {
             char *end = nullptr;
             const long t = strtol(v.c_str(), &end, 10);
@@ -1246,6 +1252,7 @@ struct DeviceIndex {
         segs_dirty = true;
         half_image_unavailable = false;
         row_image_unavailable = false;
+        row_images_reclaimed = false;
         split_searches_since_add = 0;
         light_searches_since_add = 0;
         HAC_HIP(hipMemsetAsync(ws_norm.p, 0, 16, stream));
@@ -1279,6 +1286,38 @@ struct DeviceIndex {
                     "invariant of the library, not of the input; the queries of those tiles were returned with EMPTY lists", device, n, bits);
     }
 
+    // The rescoring's row-major copies (ensure_row_image) are an optional cache of up to +100 % of the corpus: any allocation the
+    // index NEEDS gives them back before it reports an out-of-memory error (an add / search loop that used to fit
+    // could fail once the copies had been built), and they are not built again until the next reset.
+    bool drop_row_images() {
+        bool any = false;
+        for (auto &s : segs) {
+            if (s.rbuf) {
+                (void)hipFree(s.rbuf);       // (waits for the kernels that read it)
+                any = true;
+            }
+            s.rbuf = nullptr;
+            s.r_rows = 0;
+        }
+        if (any) segs_dirty = true;
+        row_images_reclaimed = true;        // (until the next reset: an add clears row_image_unavailable, this it leaves alone)
+        return any;
+    }
+    hipError_t malloc_reclaiming(void **p, size_t bytes) {
+        hipError_t e = tune.debug_oom > 0 ? hipErrorOutOfMemory : hipMalloc(p, bytes);
+        if (tune.debug_oom > 0) {
+            --tune.debug_oom;
+            if (!drop_row_images()) return hipMalloc(p, bytes);   // (nothing to give back: the real allocator decides)
+            return hipMalloc(p, bytes);
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();     // (the failed allocation's error is sticky)
+            if (drop_row_images()) e = hipMalloc(p, bytes);
+            if (e != hipSuccess) (void)hipGetLastError();
+        }
+        return e;
+    }
+
     // make room for m more rows: returns (segment index) whose rows..cap_rows can take them in pieces
     int new_segment(int64_t rows_needed, hipStream_t st) {
         if ((int)segs.size() >= MAX_SEG) HAC_TRY(consolidate(st));
@@ -1286,7 +1325,7 @@ struct DeviceIndex {
         s.cap_rows = (rows_needed + GROUP_ROWS - 1) / GROUP_ROWS * GROUP_ROWS;
         const size_t bytes = (size_t)s.cap_rows * d * sizeof(float);
         if ((bytes >> 6) > 0xFFFFFFFFull) return fail(HAC_ERR_UNSUPPORTED, "a single add() of %lld rows exceeds the segment size limit (256 GiB of fp32 rows)", (long long)rows_needed);
-        hipError_t e = hipMalloc((void **)&s.buf, bytes);   // the fp32 tiles; the fp16 image comes with the first prefilter search
+        hipError_t e = malloc_reclaiming((void **)&s.buf, bytes);   // the fp32 tiles; the fp16 image comes with the first prefilter search
         if (e != hipSuccess) return fail(HAC_ERR_OOM, "hipMalloc(%zu) for %lld rows failed: %s", bytes, (long long)rows_needed, hipGetErrorString(e));
         // zero the last group so that padding rows are finite
         const size_t gbytes = (size_t)GROUP_ROWS * d * sizeof(float);
@@ -1316,10 +1355,9 @@ struct DeviceIndex {
             if (s.rows == 0 || (s.hbuf && s.h_rows == s.rows)) continue;
             if (!s.hbuf) {
                 const size_t hbytes = (size_t)s.cap_rows * d * 2;
-                hipError_t e = hipMalloc((void **)&s.hbuf, hbytes);
+                hipError_t e = malloc_reclaiming((void **)&s.hbuf, hbytes);
                 if (e != hipSuccess) {
                     s.hbuf = nullptr;
-                    (void)hipGetLastError();   // the failed allocation's error is sticky: the next HAC_HIP(hipGetLastError()) would report it
                     return fail(HAC_ERR_OOM, "hipMalloc(%zu) for the fp16 image of %lld rows failed: %s (split = \"0\" searches without it)", hbytes,
                                 (long long)s.cap_rows, hipGetErrorString(e));
                 }
@@ -1350,6 +1388,7 @@ struct DeviceIndex {
     static constexpr int RESCORE_ROWS_AFTER = 2;
     int split_searches_since_add = 0;
     bool row_image_unavailable = false;
+    bool row_images_reclaimed = false;
     const char *rescore_from() const {   // what the plan text says: "rows" when every live segment has a current row-major copy
         bool all = !segs.empty();
         for (auto &sg : segs)
@@ -1370,18 +1409,17 @@ struct DeviceIndex {
         const bool allowed = tune.rescore_rows == 1 || (tune.rescore_rows < 0 && ntotal <= RESCORE_ROWS_MAX);
         const bool capturing = stream_is_capturing(st);
         if (!allowed) {   // switched off on a live handle, or grown past the size that gets one: the copies go (hipFree waits for their readers)
+            if (capturing) return HAC_OK;     // (a captured search frees nothing and leaves the segment table alone: the copies go with the next live search)
             for (auto &s : segs) {
                 if (!s.rbuf) continue;
-                if (!capturing) {
-                    HAC_HIP(hipFree(s.rbuf));
-                    s.rbuf = nullptr;
-                }
+                HAC_HIP(hipFree(s.rbuf));
+                s.rbuf = nullptr;
                 s.r_rows = 0;
                 segs_dirty = true;
             }
             return HAC_OK;
         }
-        if (row_image_unavailable) return HAC_OK;
+        if (row_image_unavailable || (row_images_reclaimed && tune.rescore_rows < 0)) return HAC_OK;
         if (capturing) {   // use what is current, build nothing
             bool need = false;
             for (auto &s : segs) need |= s.rows > 0 && !(s.rbuf && s.r_rows == s.rows);
@@ -1397,7 +1435,16 @@ struct DeviceIndex {
         for (auto &s : segs) {
             if (s.rows == 0 || (s.rbuf && s.r_rows == s.rows)) continue;
             if (!s.rbuf) {
-                if (hipMalloc((void **)&s.rbuf, (size_t)s.cap_rows * d * 4) != hipSuccess) {
+                const size_t rbytes = (size_t)s.cap_rows * d * 4;
+                if (tune.rescore_rows < 0) {      // auto: only while it leaves twice its own size free for whoever shares the device (the fp16 image, the encoder, torch)
+                    size_t free_b = 0, total_b = 0;
+                    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 3 * rbytes) {
+                        (void)hipGetLastError();
+                        row_image_unavailable = true;
+                        return HAC_OK;
+                    }
+                }
+                if (hipMalloc((void **)&s.rbuf, rbytes) != hipSuccess) {
                     s.rbuf = nullptr;
                     (void)hipGetLastError();
                     row_image_unavailable = true;      // until the next add / reset: nothing is retried per search
@@ -1422,7 +1469,10 @@ struct DeviceIndex {
         for (auto &s : segs) total_cap += (s.rows + GROUP_ROWS - 1) / GROUP_ROWS * GROUP_ROWS;
         Segment big;
         big.cap_rows = total_cap;
-        HAC_HIP(hipMalloc((void **)&big.buf, (size_t)total_cap * d * 4));
+        {
+            const hipError_t e = malloc_reclaiming((void **)&big.buf, (size_t)total_cap * d * 4);
+            if (e != hipSuccess) return fail(HAC_ERR_OOM, "hipMalloc(%zu) to fuse %zu segments failed: %s", (size_t)total_cap * d * 4, segs.size(), hipGetErrorString(e));
+        }
         int64_t off_rows = 0;
         for (auto &s : segs) {
             const int64_t gr = (s.rows + GROUP_ROWS - 1) / GROUP_ROWS * GROUP_ROWS;
@@ -1533,6 +1583,9 @@ struct DeviceIndex {
 
     int upload_segs(hipStream_t st) {
         if (!segs_dirty) return HAC_OK;
+        if (stream_is_capturing(st))
+            return fail(HAC_ERR_INVALID, "a search that is being captured into a graph found this index's segment table changed since its last search "
+                        "(add / reset / a dropped image): run one search outside the capture first (include/haconvdr.h: warm up before capturing)");
         // h_segs may still be the source of an earlier in-flight copy on another stream
         HAC_HIP(hipStreamSynchronize(st));
         SegDesc *h = h_segs;
@@ -1562,7 +1615,7 @@ struct DeviceIndex {
     // a library-owned event behind it: plan() waits for that event only -- never for the caller's stream, which may be gone
     // or capturing by the time someone asks.  Back-to-back device-decided searches each take their own (words, event) slot of
     // a small ring (with one slot, a search issued before the previous one had completed overwrote its words and
-    // that search's fallback count never reached split_fallback_queries); when every slot is pending the oldest is waited for.
+    // that search's fallback count never reached split_fallback_queries); when every slot is pending the new search's words are not collected.
     static constexpr int PLAN_RING = 8;
     hipEvent_t ev_plan[PLAN_RING] = {};
     u32 *h_plan = nullptr;     // pinned [PLAN_RING][2]: (queries that fell back, max err / bound as float bits)
@@ -1597,13 +1650,18 @@ struct DeviceIndex {
     void plan_collect(bool wait) {
         for (int n = 0; n < PLAN_RING; ++n) {
             const int i = (plan_head_slot + n) % PLAN_RING;   // oldest first
-            if (!plan_retire(i, wait)) break;                 // in stream order: a younger one cannot be ready either
+            if (!plan_retire(i, wait)) continue;              // (callers may use several streams: a younger search can be done before an older one)
         }
     }
-    // a slot for the search being enqueued
+    // a slot for the search being enqueued, or -1: every slot still belongs to a search in flight (the *_device entry points never
+    // wait on the host: that search's status words are then simply not collected -- its results do not depend on them)
+    long long plan_uncollected = 0;
     int plan_slot() {
         const int i = plan_head_slot;
-        if (slot_pending[i]) (void)plan_retire(i, true);      // the ring is full: the oldest search must finish first
+        if (slot_pending[i] && !plan_retire(i, false)) {
+            ++plan_uncollected;
+            return -1;
+        }
         plan_head_slot = (i + 1) % PLAN_RING;
         return i;
     }
@@ -1840,9 +1898,22 @@ struct DeviceIndex {
     static constexpr int LIGHT_SEARCHES_BEFORE_IMAGE = 2;
     int light_searches_since_add = 0;
     // (not a pure predicate: a light search of an index without an image counts towards building one)
+    bool half_image_current() const {   // every live segment's image covers all of its rows: a search can use it as it is
+        bool any = false;
+        for (auto &s : segs) {
+            if (s.rows == 0) continue;
+            if (!(s.hbuf && s.h_rows == s.rows)) return false;
+            any = true;
+        }
+        return any;
+    }
     bool decide_prefilter(int64_t nq, int k, bool capturing = false) {
         if (tune.split == 0) return false;   // 0: never, 1: whenever supported (tests), -1: by size
         if (!split_supported(k)) return false;
+        // a search that is being captured into a graph neither allocates nor uploads nor synchronizes (stream_is_capturing): it takes
+        // the prefilter only over an image that is complete and a segment table that is on the device -- whatever split says and
+        // however many pairs there are -- and the exact kernels (same bits) otherwise
+        if (capturing && !(half_image_current() && !segs_dirty)) return false;
         if (tune.split == 1) return true;
         const double pairs = (double)nq * (double)ntotal;
         if (nq >= 48 && pairs >= 1.0e8) return true;
@@ -2062,7 +2133,14 @@ struct DeviceIndex {
             snprintf(plan_head, sizeof plan_head, "split: scanh_kernel<%d> grid=(%ld,%d) NQ=%d K2=%d chunks=%d lds=%zu seed=%d passes=%d rescore=%s%s", terms, P_last,
                      n_qtiles_last, SH_NQ, K2, n_chunks, lds, seeded, passes_last, rescore_from(), qt_act_last == 8 ? " tiles=half" : qt_act_last == 4 ? " tiles=quarter" : "");
             snprintf(last_plan, sizeof last_plan, "%s fallback=device-side/%lld", plan_head, (long long)nq);
-            const int slot = plan_slot();
+            // (a search that is being captured takes no slot: every replay would write the slot's pinned words again, under whichever
+            // live search owns the slot by then)
+            const int slot = stream_is_capturing(st) ? -1 : plan_slot();
+            if (slot < 0) {
+                snprintf(last_plan, sizeof last_plan, "%s fallback=device-side/%lld (status not collected)", plan_head, (long long)nq);
+                plan_text_slot = -1;
+                return HAC_OK;
+            }
             HAC_HIP(hipMemcpyAsync(h_plan + 2 * slot, ws_stat.p, 8, hipMemcpyDeviceToHost, st));
             HAC_HIP(hipEventRecord(ev_plan[slot], st));
             slot_pending[slot] = true;

@@ -237,16 +237,18 @@ def test_woven_attention_is_bit_identical_to_the_one_block_kernel(shape):
     for enc in (encoder(2, 0.08), _enc12()):
         outs = {}
         try:
-            for mode in ("off", "auto"):
+            for mode in ("off", "all", "auto"):
                 enc.set_option("attn_pipe", mode)
                 outs[mode] = enc(ids.astype(np.int32), mask.astype(np.int32))
                 plan = _plan(enc)
-                assert plan["attn"] == "stream" and plan["attn_form"] == ("woven" if mode == "auto" else "single"), plan
-                if mode == "auto":
+                woven = mode == "all" or (mode == "auto" and L > 384)      # ("auto": the long class of batches padded beyond 384 rows)
+                assert plan["attn"] == "stream" and plan["attn_form"] == ("woven" if woven else "single"), plan
+                if woven:
                     assert enc.attention_redo() == 0
         finally:
             enc.set_option("attn_pipe", "auto")
-        assert np.isfinite(outs["auto"]).all()
+        assert np.isfinite(outs["all"]).all()
+        np.testing.assert_array_equal(outs["all"], outs["off"])
         np.testing.assert_array_equal(outs["auto"], outs["off"])
 
 
@@ -264,7 +266,7 @@ def test_woven_attention_hands_rows_outside_the_window_to_the_fixup_pass(scale):
     mask = (np.arange(512)[None, :] < lens[:, None]).astype(np.int32)
     outs, redo = {}, None
     for mode in ("off", "auto"):
-        enc.set_option("attn_pipe", mode)
+        enc.set_option("attn_pipe", "all" if mode == "auto" else mode)
         outs[mode] = enc(ids.astype(np.int32), mask.astype(np.int32))
         if mode == "auto":
             redo = enc.attention_redo()
@@ -283,6 +285,7 @@ def test_woven_attention_hands_rows_outside_the_window_to_the_fixup_pass(scale):
     again = enc(ids.astype(np.int32), mask.astype(np.int32))
     np.testing.assert_array_equal(again, outs["auto"])
     assert enc.attention_redo() == redo
+    enc.set_option("attn_pipe", "auto")
 
 
 @pytest.mark.parametrize("lo,hi,n_seq", [(1, 96, 700), (200, 300, 400), (257, 512, 300)])
@@ -633,7 +636,7 @@ def test_options_outside_the_documented_set_are_errors():
         with pytest.raises(HacError):
             enc.set_option(name, value)
     for name, value in (("gemm", "auto"), ("attn", "stream"), ("graph", "off"), ("graph", "auto"), ("ksplit", "off"), ("ksplit", "auto"),
-                        ("g8_stagger", "off"), ("g8_stagger", "auto"), ("ksplit_pin", "2/4"), ("ksplit_pin", "0/0"), ("attn_qs_pin", "4"), ("attn_qs_pin", "0"), ("attn_pipe", "off"), ("attn_pipe", "auto")):
+                        ("g8_stagger", "off"), ("g8_stagger", "auto"), ("ksplit_pin", "2/4"), ("ksplit_pin", "0/0"), ("attn_qs_pin", "4"), ("attn_qs_pin", "0"), ("attn_pipe", "off"), ("attn_pipe", "all"), ("attn_pipe", "auto")):
         enc.set_option(name, value)
     idx = FlatIPIndex(768)
     for name, value in (("split", "on"), ("split_terms", "2"), ("force_scan16", "yes"), ("scanq_nt", "5"), ("scanq_waves", "6"),

@@ -867,6 +867,12 @@ def test_device_search_is_graph_capturable_on_the_prefilter_path(oracle):
     oD, oI = oracle.flat_ip_search(x, q, 100)
     assert_same(D1.cpu().numpy(), I1.cpu().numpy(), oD, oI)
     assert_same(D0.cpu().numpy(), I0.cpu().numpy(), oD, oI)
+    # (a captured search takes no slot of the status ring -- every replay would write its pinned words under whichever live search
+    # owns the slot by then -- so its plan text says so; the live search behind it reports as usual)
+    assert "status not collected" in idx.last_plan(), idx.last_plan()
+    D2, I2 = idx.search_tensor(qt, 100)
+    torch.cuda.synchronize()
+    assert_same(D2.cpu().numpy(), I2.cpu().numpy(), oD, oI)
     nfail, nq_, ratio = _plan_fields(idx)
     assert nq_ == len(q) and nfail == 0 and ratio < 0.25, idx.last_plan()
 
@@ -969,6 +975,41 @@ def test_half_precision_image_is_built_lazily(oracle):
     idx.set_option("split", "0")
     D0, I0 = idx.search(q, 100)
     assert_same(D, I, D0, I0)
+
+
+def test_row_major_copies_are_given_back_when_the_index_needs_the_memory(oracle):
+    """the rescoring's row-major copies are an optional cache of up to +100 % of the corpus; an allocation the
+    index needs (a new segment here; the fp16 image and the fused segment go through the same helper) gives them back instead of
+    failing with HAC_ERR_OOM.  The full device is simulated ("debug_oom": the next allocation behaves as if its first attempt
+    had failed): the add succeeds, the copies are gone (plan text, free memory), are not rebuilt until the next reset, and every
+    answer is the same bits."""
+    import torch
+    from haconvdr_amd.index import FlatIPIndex
+    x, q, _ = cases.search_case_inputs("gauss", 0x0071, 150000, 80)
+    idx = FlatIPIndex(768)
+    idx.set_option("split", "1")
+    idx.set_option("rescore_rows", "1")
+    idx.add(x[:100000])
+    D0, I0 = idx.search(q, 100)
+    assert "rescore=rows" in idx.last_plan(), idx.last_plan()
+    torch.cuda.synchronize()
+    free_with = torch.cuda.mem_get_info()[0]
+    idx.set_option("rescore_rows", "auto")
+    idx.set_option("debug_oom", "1")
+    idx.add(x[100000:])                                            # a new segment: the copies go, the add succeeds
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] > free_with - 2 * 50000 * 768 * 4 + 0.9 * 100000 * 768 * 4     # (the new segment came out of the copy's memory)
+    for n in range(4):                                             # ... and stay away (no third-search rebuild) until a reset
+        D1, I1 = idx.search(q, 100)
+        assert "rescore=tiles" in idx.last_plan(), (n, idx.last_plan())
+    assert_same(D1, I1, *oracle.flat_ip_search(x, q, 100))
+    assert_same(D0, I0, *oracle.flat_ip_search(x[:100000], q, 100))
+    idx.reset()
+    idx.add(x[:100000])
+    for n in range(3):
+        D2, I2 = idx.search(q, 100)
+    assert "rescore=rows" in idx.last_plan(), idx.last_plan()
+    assert_same(D2, I2, D0, I0)
 
 
 def test_row_major_copy_for_the_rescoring_is_lazy_optional_and_changes_no_bit(oracle):
