@@ -288,7 +288,7 @@ def main():
     # the shader clock the part sustained inside the last FFN-up launch of the timed steps (boxes of one pool differ by several
     # percent on the same binary: this is the figure to normalise fractions of a peak by); None without an encoder
     clk_read = enc.last_clock_mhz() if enc is not None else None
-    shader_mhz, clk_seconds = clk_read if clk_read else (float("nan"), 0.0)
+    shader_mhz, clk_seconds = clk_read if clk_read else (None, 0.0)    # (None: no large-batch FFN-up launch ran with class profiling on)
     scan_ms = index.profile_drain()
     plan = index.last_plan()
     enc_plan = enc.last_plan() if enc is not None else None
@@ -368,21 +368,25 @@ def main():
                                       "flops": "12 x (14,155,776 T + 4 T^2 768) + 2 x 768^2 per padded query, SURVEY 8d"},
                     "encoder_plan": enc_plan, "search": search_roof}
         # the same fractions against the peak at the clock the part actually held (2.5 PF dense bf16 / fp16 is quoted at 2.4 GHz)
-        clk_scale = shader_mhz / 2400.0
-        roofline["sustained_shader_clock_MHz"] = round(shader_mhz, 1)
-        roofline["frac_of_clock_held_peak"] = round(tf / (PEAK_F16_MFMA_TF * clk_scale), 4)
-        roofline["encoder_stack"]["mfma_bf16_frac_of_clock_held_peak"] = round(enc_flops / (stack_avg * 1e-3) / (2.5e15 * clk_scale), 4)
-        if search_roof.get("bound") == "mfma" and search_roof.get("peak") == PEAK_F16_MFMA_TF:
-            search_roof["frac_of_clock_held_peak"] = round(search_roof["frac"] / clk_scale, 4)
-        roofline["clock_note"] = ("sustained_shader_clock_MHz = d(s_memtime) / d(s_memrealtime) x 100 MHz between the first and the last instruction of "
-                                  f"workgroup 0 of the LAST FFN-up launch of the timed steps ({clk_seconds * 1e3:.3f} ms; hac_encoder_last_clock); "
-                                  "*_of_clock_held_peak = the same achieved rate over peak x clock / 2400 MHz")
+        if shader_mhz:
+            clk_scale = shader_mhz / 2400.0
+            roofline["sustained_shader_clock_MHz"] = round(shader_mhz, 1)
+            roofline["frac_of_clock_held_peak"] = round(tf / (PEAK_F16_MFMA_TF * clk_scale), 4)
+            roofline["encoder_stack"]["mfma_bf16_frac_of_clock_held_peak"] = round(enc_flops / (stack_avg * 1e-3) / (2.5e15 * clk_scale), 4)
+            if search_roof.get("bound") == "mfma" and search_roof.get("peak") == PEAK_F16_MFMA_TF:
+                search_roof["frac_of_clock_held_peak"] = round(search_roof["frac"] / clk_scale, 4)
+            roofline["clock_note"] = ("sustained_shader_clock_MHz = d(s_memtime) / d(s_memrealtime) x 100 MHz between the first and the last instruction of "
+                                      f"workgroup 0 of the LAST FFN-up launch of the timed steps ({clk_seconds * 1e3:.3f} ms; hac_encoder_last_clock); "
+                                      "*_of_clock_held_peak = the same achieved rate over peak x clock / 2400 MHz")
+        else:
+            roofline["sustained_shader_clock_MHz"] = None
         # every kernel class of the step, from the event pairs of the TIMED steps: per-step time, share of the step, fraction of
         # the 2.5 PF bf16 / fp16 peak -- so that "dominant" can be checked from this line alone
         fl_step = {"qkv": 2.0 * T_tok * 768 * 2304 * 12, "out_proj": 2.0 * T_tok * 768 * 768 * 11, "ffn_up": 2.0 * T_tok * 768 * 3072 * 11,
                    "ffn_down": 2.0 * T_tok * 3072 * 768 * 11, "attention": 4.0 * Lq * 768 * T_tok * 12}
         kname = {"qkv": "gemm8_kernel<EPI8_QKV>", "out_proj": "gemm8_kernel<EPI8_RESID> K=768", "ffn_up": "gemm8_kernel<EPI8_GELU>",
-                 "ffn_down": "gemm8_kernel<EPI8_RESID> K=3072", "attention": "attention_stream_kernel<16|8>", "layernorm": "ln_combine_kernel"}
+                 "ffn_down": "gemm8_kernel<EPI8_RESID> K=3072", "attention": "attention_pipe_kernel<8> + attention_stream_kernel<16|8> (woven form for whole long items, the one-block form for the rest)",
+                 "layernorm": "ln_combine_kernel"}
         kernels = []
         for name, msl in class_ms.items():
             if not msl:
@@ -402,9 +406,24 @@ def main():
         resid = sum(e["ms_per_step"] for e in kernels if e["class"] in ("out_proj", "ffn_down"))
         kernels.sort(key=lambda e: -e["ms_per_step"])
         roofline["kernels"] = kernels
-        roofline["dominant_note"] = (f"largest per step: {kernels[0]['kernel']} ({kernels[0]['ms_per_step']} ms); gemm8_kernel<EPI8_RESID> as ONE "
-                                     f"instantiation (out-proj + FFN-down) {round(resid, 3)} ms; the top-level figure is FFN-up, the large GEMM "
-                                     "class with the lowest fraction of its peak after out-proj")
+        # The top-level roofline object describes the LARGEST kernel of the step (the line used to present FFN-up as "the
+        # dominant kernel" while its own note said the prefilter scan was larger); the largest encoder GEMM class stays beside it.
+        if kernels[0]["class"] == "search_scan":
+            enc_dom = {key: roofline.pop(key) for key in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "mfma_util", "kernel_ms",
+                                                          "launches_per_step", "flops_per_launch", "share_of_step", "frac_of_clock_held_peak") if key in roofline}
+            roofline.pop("search")
+            top = dict(search_roof)
+            top["share_of_step"] = kernels[0]["share_of_step"]
+            top["launches_per_step"] = kernels[0]["launches_per_step"]
+            top.update(roofline)
+            roofline = top
+            roofline["encoder_dominant"] = enc_dom
+            roofline["dominant_note"] = (f"largest per step: {kernels[0]['kernel']} ({kernels[0]['ms_per_step']} ms) = this object's kernel / achieved / peak / frac; "
+                                         f"encoder_dominant = FFN-up, the largest encoder class ({enc_dom['kernel_ms']} ms x {enc_dom['launches_per_step']}); "
+                                         f"gemm8_kernel<EPI8_RESID> as ONE instantiation (out-proj + FFN-down) {round(resid, 3)} ms")
+        else:
+            roofline["dominant_note"] = (f"largest per step: {kernels[0]['kernel']} ({kernels[0]['ms_per_step']} ms); gemm8_kernel<EPI8_RESID> as ONE "
+                                         f"instantiation (out-proj + FFN-down) {round(resid, 3)} ms")
     else:
         roofline = search_roof
     roofline.update(traffic_note)
@@ -467,25 +486,34 @@ def main():
             extras["real_query_lengths"] = {"queries_per_sec": round(nq / t_var, 1), "ms_per_step": round(t_var * 1e3, 3),
                                             "mean_len": round(float(qlens.mean()), 1), "lens": f"uniform in [64, {Lq}], prefix mask"}
             # every kernel class of the encoder (hipEvent pairs around each launch; untimed pass)
+            # (median of three forwards: one sample is not a measurement -- a committed r05 line carried a 57 ms FFN-up hiccup)
             enc.set_profiling(True, classes="all")
-            enc(ids_t, mask_t)
-            sync()
-            stack = float(np.sum(enc.profile_drain()))
+            stacks, samples = [], {name: [] for name in enc.KERNEL_CLASSES}
+            launches = {}
+            for _ in range(3):
+                enc(ids_t, mask_t)
+                sync()
+                stacks.append(float(np.sum(enc.profile_drain())))
+                for name in enc.KERNEL_CLASSES:
+                    ms = enc.profile_drain_class(name)
+                    if ms:
+                        samples[name].append(float(np.sum(ms)))
+                        launches[name] = len(ms)
+            enc.set_profiling(False)
+            stack = float(np.median(stacks))
             per_class = {}
             fl_class = {"qkv": 2.0 * T_tok * 768 * 2304 * 12, "out_proj": 2.0 * T_tok * 768 * 768 * 11, "ffn_up": 2.0 * T_tok * 768 * 3072 * 11,
                         "ffn_down": 2.0 * T_tok * 3072 * 768 * 11, "attention": 4.0 * Lq * 768 * T_tok * 12}
             for name in enc.KERNEL_CLASSES:
-                ms = enc.profile_drain_class(name)
-                if not ms:
+                if not samples[name]:
                     continue
-                tot = float(np.sum(ms))
-                per_class[name] = {"ms_per_forward": round(tot, 3), "launches": len(ms)}
+                tot = float(np.median(samples[name]))
+                per_class[name] = {"ms_per_forward": round(tot, 3), "launches": launches[name], "min_max_ms": [round(min(samples[name]), 3), round(max(samples[name]), 3)]}
                 if name in fl_class:
                     per_class[name]["achieved_TFLOPs"] = round(fl_class[name] / (tot * 1e-3) / 1e12, 1)
                     per_class[name]["mfma_bf16_frac"] = round(fl_class[name] / (tot * 1e-3) / 2.5e15, 4)
-            enc.set_profiling(False)
-            extras["encoder_kernels"] = {"layer_stack_ms": round(stack, 3), "per_class": per_class,
-                                         "note": "one forward of this rank's queries with an event pair around every launch"}
+            extras["encoder_kernels"] = {"layer_stack_ms": round(stack, 3), "per_class": per_class, "attention_form": enc.last_plan().split("attn_form=")[-1].split()[0],
+                                         "note": "median of three forwards of this rank's queries with an event pair around every launch"}
         # ---- the north-star corpus: 10M x 768 over the N GPUs, same step ----------------------------------
         if rows != ns_rows:
             lo2, hi2 = shard_range(ns_rows, rank, world)
@@ -674,7 +702,7 @@ def host_cores():
     return affinity, quota
 
 
-def search_blocked_baseline(np, xh, qh, k, threads, oI):
+def search_blocked_baseline(np, xh, qh, k, threads, oI, oD=None):
     """faiss-like CPU search: S = q @ x_blk^T (sgemm) over 1024-row blocks, running top-k by argpartition.  Labelled
     "faiss-like, not bit-exact"; the ids are compared with the exact oracle's only as a recall figure."""
     from threadpoolctl import threadpool_limits
@@ -701,7 +729,16 @@ def search_blocked_baseline(np, xh, qh, k, threads, oI):
             ts.append(time.perf_counter() - tp)
     t = float(np.median(ts))
     recall = float(np.mean([len(set(bI[i]) & set(oI[i])) / float(k) for i in range(nq_s)]))
-    return {"label": "faiss-like (blocked sgemm + top-k update), numpy/OpenBLAS, NOT bit-exact", "queries_per_sec_over_slice": round(nq_s / t, 2),
+    vs = None
+    if oD is not None:
+        # what the canonical (fma-chain) order costs against a BLAS-order IndexFlatIP, measured: ids that moved, and that every move
+        # sits inside a tie band (oracle/blas_order.py; tests/test_search_gpu.py asserts it on GPU results)
+        from oracle import blas_order
+        try:
+            vs = blas_order.tie_band_report(xh, qh, k, oD, oI)
+        except Exception as ex:
+            vs = {"error": repr(ex)}
+    return {"vs_blas_order": vs, "label": "faiss-like (blocked sgemm + top-k update), numpy/OpenBLAS, NOT bit-exact", "queries_per_sec_over_slice": round(nq_s / t, 2),
             "GFLOPs": round(2.0 * nq_s * n * D_EMB / t / 1e9, 1), "block_rows": BLK, "threads": int(threads), "runs_s": [round(v, 3) for v in ts],
             "recall_vs_exact_ids": round(recall, 5)}
 
@@ -760,7 +797,7 @@ def cpu_baseline(np, torch, synth, enc, D, I, q_pre, kept, rows, nq, k, Lq, tok,
     # beside the exact port: the SHAPE of faiss-cpu's IndexFlatIP.search (blocked sgemm over 1024-row database blocks, then a
     # top-k update), with numpy / OpenBLAS -- not bit-exact (BLAS summation order), a speed reference only
     try:
-        search["blocked_sgemm"] = search_blocked_baseline(np, xh, qh, k, cores, oI)
+        search["blocked_sgemm"] = search_blocked_baseline(np, xh, qh, k, cores, oI, oD)
     except Exception as ex:
         search["blocked_sgemm"] = {"error": repr(ex)}
     res = {"unit": "queries/s", "kind": "port", "cores": cores, "logical_cpus": affinity, "cgroup_cpu_quota": quota, "faiss": faiss_note, "search": search}

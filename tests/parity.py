@@ -8,7 +8,8 @@ DIFFERENT sequences of tests/golden/encoder_l2_full384.npz are 1.7e-4 apart in 1
 * raw cosine:      1−cos(out_i, ref_i) ≤ min(contract 1e-3, FRACTION · min_{i≠j} 1−cos(ref_i, ref_j))
 * centred cosine:  the same after subtracting the REFERENCE's batch-mean embedding from out and ref (the common direction
                    all rows share is removed: what is left is what distinguishes the rows)
-* relative L2:     ‖out_i − ref_i‖ / ‖ref_i − mean‖ ≤ REL_L2  (a wrong row scores ≈ √2)
+* relative L2:     ‖out_i − ref_i‖ / ‖ref_i − mean‖ ≤ REL_L2 = 0.25 (a wrong row scores ≈ √2); 0.35 only for fixtures whose rows are
+                   closer together than the 1e-3 contract (below)
 
 ``spread`` reports the fixture's own inter-sequence distances; ``embeddings_match`` is the boolean twin used by the negative
 controls (rows permuted by one must NOT match).
@@ -17,7 +18,14 @@ import numpy as np
 
 CONTRACT = 1e-3      # BASELINE.json north_star: embedding cosines within 1e-3 of the reference CPU path
 FRACTION = 0.1       # of the fixture's minimum inter-sequence distance
-REL_L2 = 0.35        # of the row's distance from the batch mean: a quarter of what another sequence's embedding scores (~ sqrt 2)
+REL_L2 = 0.25        # of the row's distance from the batch mean: a sixth of what another sequence's embedding scores (~ sqrt 2)
+# Exemption, not a general loosening: fixtures whose reference rows are closer together than the 1e-3 contract itself --
+# the N(0, 0.02^2)-weight fixtures l2_mixed / l2_full384 (rows 1.2e-4 / 1.7e-4 apart) and bench.py's timed batch (7.0e-4): every row is
+# the common direction plus a difference of ~1 % of its norm, and the bf16 path's rounding noise (1-cos ~7e-6, a fortieth of the rows'
+# distance) is a third of that difference in L2 (measured 0.322 on l2_full384 through gemm8, 0.321 on the timed batch).  Every fixture
+# with rows >= 1e-3 apart measures <= 0.13 and keeps the 0.25 bound.
+REL_L2_DEGENERATE = 0.35
+DEGENERATE_BELOW = 1e-3
 
 
 def one_minus_cos(a, b):
@@ -53,7 +61,7 @@ def measure(out, ref):
         "centred": float(one_minus_cos(out - mu, ref - mu).max()),
         "centred_bound": FRACTION * sp["centred_min"],
         "rel_l2": float((np.linalg.norm(out - ref, axis=1) / np.linalg.norm(ref - mu, axis=1)).max()),
-        "rel_l2_bound": REL_L2,
+        "rel_l2_bound": REL_L2 if sp["raw_min"] >= DEGENERATE_BELOW else REL_L2_DEGENERATE,
         "spread": sp,
     }
 
