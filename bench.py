@@ -82,24 +82,39 @@ def spawn_ranks(n, argv):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    import tempfile
+    procs, errs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
-    rc = 0
-    alive = list(procs)
+        # every rank's stderr goes to a file of its own: forwarded when the rank ends, and quoted in the error line if it failed
+        errs.append(tempfile.TemporaryFile(mode="w+", prefix=f"bench_rank{r}_", suffix=".err"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stderr=errs[-1]))
+    rc, first_bad = 0, None
+    alive = list(range(n))
     while alive:
         time.sleep(0.2)
-        for p in list(alive):
-            code = p.poll()
+        for r in list(alive):
+            code = procs[r].poll()
             if code is None:
                 continue
-            alive.remove(p)
+            alive.remove(r)
             if code != 0 and rc == 0:
-                rc = code
+                rc, first_bad = code, r
                 for other in alive:          # a dead rank leaves the others waiting in a collective
-                    other.terminate()
+                    procs[other].terminate()
+    tails = {}
+    for r in range(n):
+        errs[r].seek(0)
+        text = errs[r].read()
+        errs[r].close()
+        if text:
+            sys.stderr.write(text if text.endswith("\n") else text + "\n")
+        tails[r] = text[-2000:]
+    if rc != 0:
+        # the run's record says which rank failed and why (a per-rank failure must be readable from the line, not only an exit code)
+        print(json.dumps({"error": f"rank {first_bad} of {n} exited with code {rc}; the other ranks were terminated", "n_gpus": n, "failed_rank": first_bad,
+                          "exit_code": rc, "stderr_tail": tails.get(first_bad, "")}), flush=True)
     sys.exit(rc)
 
 
@@ -164,6 +179,11 @@ def main():
     import torch
     import torch.distributed as dist
 
+    t_begin = time.perf_counter()
+    timeline = {}
+
+    def mark(name):        # wall clock of this rank since its start (the driver allows the whole run 600 s)
+        timeline[name] = round(time.perf_counter() - t_begin, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -221,6 +241,7 @@ def main():
     index = FlatIPIndex(D_EMB, devices=(local_rank,))
     kept = fill_index(index, lo, hi, dev, block_rows, keep_first=1_000_000 if want_cpu else 0)
     searcher = ShardedSearcher(index, shard_base=lo)
+    mark("corpus_resident")
 
     nq_loc = (nq + world - 1) // world                                   # queries are encoded data-parallel
     enc = None
@@ -285,6 +306,7 @@ def main():
     sync()
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
+    mark("timed_steps_done")
     # the shader clock the part sustained inside the last FFN-up launch of the timed steps (boxes of one pool differ by several
     # percent on the same binary: this is the figure to normalise fractions of a peak by); None without an encoder
     clk_read = enc.last_clock_mhz() if enc is not None else None
@@ -622,21 +644,81 @@ def main():
                 psg[f"docs_per_sec_{name}"] = round(float(rate.item()), 1)
                 psg[f"docs_per_sec_per_gpu_{name}_min"] = round(float(lo_rate.item()), 1)
             psg["mfma_bf16_frac_padded"] = round(12.0 * (14155776.0 * Lp + 4.0 * Lp * Lp * 768.0) * psg["docs_per_sec_padded"] / world / 2.5e15, 4)
+            psg["block_ownership"] = passage_block_ownership_check(np, torch, dist, synth, enc, rank, world, barrier)
             extras["passages_L384"] = psg
 
     failed = None
     if rank == 0:
         out.update(extras)
+        mark("extras_done")
+        out["wall_clock_s"] = dict(timeline, note="rank 0, since the process started (python + torch import included from 'corpus_resident' on); the driver's limit for the run is 600 s")
         print(json.dumps(out), flush=True)
         v = (extras.get("north_star_10M") or {}).get("verify")
         if v is not None and not (v["ids_equal"] and v["scores_equal"]):
             failed = "the sharded step's merged (D, I) differ from the single-GPU exact search (north_star_10M.verify)"
         if world > 1 and "error" in out.get("collective", {}):
             failed = out["collective"]["error"]
+        own = (extras.get("passages_L384") or {}).get("block_ownership")
+        if own is not None and not own["every_block_once_by_its_owner"]:
+            failed = "passage blocks were not written exactly once, each by its owner (passages_L384.block_ownership)"
     if world > 1:
         dist.destroy_process_group()
     if failed:
         raise SystemExit("bench.py: " + failed)       # after the JSON line: the record shows what was measured AND that it is wrong
+
+
+def passage_block_ownership_check(np, torch, dist, synth, enc, rank, world, barrier):
+    """configs[4] on N ranks has no collective: rank r encodes and writes the blocks b = r (mod N) (haconvdr_amd/passages.py:
+    encode_passages, the mirror of gen_doc_embeddings.py:65-158, whose DataParallel loop writes every block from one process).  The
+    self-check of that split, since nobody can rehearse the 8-GPU run: a small synthetic collection (2 N + 1 blocks of 64 passages, the
+    last one short) goes through the real loop on every rank, each rank into a directory of its own; then every block must exist
+    exactly once, in its owner's directory, with the ids of its range."""
+    import shutil
+    import tempfile
+    from haconvdr_amd import passages as P
+
+    class Collection:            # what encode_passages needs of TokenizedPassages: len() and batch(lo, hi) -> (ids int32 [m, L], lens int64 [m])
+        def __init__(self, n, L):
+            self.tok, _ = synth.token_batch(0xB10C, n, L, fixed_len=L)
+            self.lens = 8 + (synth.uniform_u32(0xB10D, n) % np.uint32(L - 8 + 1)).astype(np.int64)
+
+        def __len__(self):
+            return len(self.lens)
+
+        def batch(self, lo, hi):
+            ids = self.tok[lo:hi].copy()
+            ids[np.arange(ids.shape[1])[None, :] >= self.lens[lo:hi, None]] = 0
+            return ids.astype(np.int32), self.lens[lo:hi]
+    n_blocks, per_block = 2 * world + 1, 64
+    n = (n_blocks - 1) * per_block + 17
+    coll = Collection(n, 64)
+    root = [os.path.join(tempfile.gettempdir(), f"hac_bench_blocks_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")]   # (one node: the ranks see the same path)
+    if rank == 0:
+        shutil.rmtree(root[0], ignore_errors=True)
+        os.makedirs(root[0])
+    barrier()
+    mine = os.path.join(root[0], f"rank{rank}")
+    wrote = P.encode_passages(enc, coll, mine, per_gpu_eval_batch_size=32, n_gpu=1, rank=rank, world_size=world, expect_per_block_passage_num=per_block)
+    barrier()
+    res = None
+    if rank == 0:
+        problems, total = [], 0
+        for b in range(n_blocks):
+            holders = [r for r in range(world) if os.path.exists(os.path.join(root[0], f"rank{r}", f"passage_emb_block_{b}.pb"))]
+            if holders != [b % world]:
+                problems.append(f"block {b}: written by ranks {holders}, owner {b % world}")
+                continue
+            emb, ids = P.read_embedding_block(os.path.join(root[0], f"rank{b % world}"), b)
+            lo, hi = b * per_block, min(n, (b + 1) * per_block)
+            total += len(ids)
+            if not (np.array_equal(np.asarray(ids), np.arange(lo, hi)) and emb.shape == (hi - lo, D_EMB) and np.isfinite(emb).all()):
+                problems.append(f"block {b}: ids / shape / values")
+        res = {"blocks": n_blocks, "passages": n, "passages_in_blocks": total, "rank0_wrote": int(wrote), "every_block_once_by_its_owner": not problems and total == n}
+        if problems:
+            res["problems"] = problems[:8]
+        shutil.rmtree(root[0], ignore_errors=True)
+    barrier()
+    return res
 
 
 # ------------------------------------------------------------------------------ committed PMC passes (roofline.traffic)

@@ -19,7 +19,7 @@ def test_bench_two_rank_rehearsal_matches_single_process(tmp_path):
     dump = str(tmp_path / "step.npz")
     env = dict(os.environ, HAC_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "2000000", "--steps", "2", "--warmup", "1",
-           "--no-cpu-baseline", "--extras", "verify", "--north-star-rows", "1500000", "--dump-results", dump]
+           "--no-cpu-baseline", "--extras", "default", "--north-star-rows", "1500000", "--dump-results", dump]      # (default = what the driver's N > 1 runs execute)
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
@@ -36,6 +36,12 @@ def test_bench_two_rank_rehearsal_matches_single_process(tmp_path):
     assert v["queries"] == 8 and v["rows"] == 1_500_000 and v["ids_equal"] is True and v["scores_equal"] is True and "scan" in v["referee"]
     a = js["cfg4_shard_step"]
     assert a["queries_per_sec"] > 0 and a["min_over_ranks"] <= a["queries_per_sec"] <= a["max_over_ranks"] * 1.0001 and a["rows_per_gpu"] == 1_000_000
+    # configs[4] on N ranks: no collective, every rank writes the blocks it owns -- checked through the real encode loop (round 6)
+    own = js["passages_L384"]["block_ownership"]
+    assert own["every_block_once_by_its_owner"] is True and own["blocks"] == 5 and own["passages_in_blocks"] == own["passages"], own
+    assert js["passages_L384"]["docs_per_sec_padded"] > 0 and js["passages_L384"]["gpus"] == 2
+    w = js["wall_clock_s"]
+    assert 0 < w["corpus_resident"] <= w["timed_steps_done"] <= w["extras_done"] < 600, w
     assert js["config"]["corpus_rows"] == 2_000_000 and js["config"]["rows_per_gpu"] == 1_000_000
     assert js["value"] > 0 and abs(js["value"] - 1000 / (js["ms_per_step"] * 1e-3)) < 1e-3 * js["value"]
     g = np.load(dump)

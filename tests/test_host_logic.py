@@ -1,6 +1,7 @@
 """CPU-only tests: host logic, the C-ABI surface, determinism of the synthetic generators and the
 world_size-2 gloo run of the sharded-search plumbing.  No compute call touches a GPU here."""
 import hashlib
+import json
 import os
 import re
 import socket
@@ -192,6 +193,9 @@ def test_bench_starts_its_own_ranks():
     assert len({l.split()[-1] for l in lines}) == 1           # one rendezvous port for all ranks
     bad = subprocess.run(cmd + ["7"], capture_output=True, text=True, timeout=120)
     assert bad.returncode == 7
+    # ... and says which rank failed, with the tail of that rank's stderr, in a JSON line of its own (the run's record must show it)
+    err = [json.loads(l) for l in bad.stdout.splitlines() if l.startswith("{")]
+    assert len(err) == 1 and err[0]["failed_rank"] == 1 and err[0]["exit_code"] == 7 and err[0]["n_gpus"] == 3 and "stderr_tail" in err[0], bad.stdout
 
 
 def test_large_batch_gemm_kernels_keep_everything_in_registers():

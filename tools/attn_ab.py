@@ -42,7 +42,7 @@ def main():
         for which, e in (("12-layer", enc), ("sens 2-layer", sens), ("peaked 2-layer", peaked)):
             outs = {}
             for mode in ("off", "auto"):
-                e.set_option("attn_pipe", mode)
+                e.set_option("attn_pipe", "all" if mode == "auto" else mode)
                 outs[mode] = e(ids_t, mask_t).cpu().numpy()
                 plan = e.last_plan()
             same = np.array_equal(outs["off"], outs["auto"])
