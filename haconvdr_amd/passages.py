@@ -172,6 +172,10 @@ def encode_passages(model, passages, out_dir, per_gpu_eval_batch_size=250, n_gpu
         for s in range(lo, hi, batch):
             e = min(hi, s + batch)
             ids, lens = passages.batch(s, e)
+            # (the reader hands out slices of a READ-ONLY mmap: torch.from_numpy of those warns, and a write through such a tensor
+            # is undefined behaviour -- the batch is copied once, into writable memory, before torch sees it)
+            ids = np.require(ids, requirements=["C", "W"])
+            lens = np.require(lens, requirements=["C", "W"])
             ids_t = torch.from_numpy(ids).to(dev, non_blocking=True)
             # attention_mask = [1]*passage_len + [0]*pad_len  (gen_doc_embeddings.py:38-40)
             mask_t = (torch.arange(ids.shape[1], device=dev)[None, :] < torch.from_numpy(lens).to(dev)[:, None]).to(torch.int32)

@@ -114,6 +114,38 @@ def test_trec_metrics_read_both_qrel_forms(tmp_path):
     assert print_trec_res(str(tmp_path / "run.tsv"), str(tmp_path / "qrel.tsv")) == a
 
 
+def test_trec_metrics_table_from_trec_evals_definitions(tmp_path):
+    """print_trec_res against trec_eval's published definitions on a fixture worked out BY HAND (the literals below come from the
+    formulas, not from this package) -- pytrec_eval itself is absent here, so this is what pins f-3's metric block
+    (src/test_HAConvDR_topiocqa.py:288-353) short of the real thing.  What the cases discriminate:
+      q1  ties in the run's score: trec_eval ranks by score descending, then by document id DESCENDING as a string ("d9" before "d10";
+          a numeric or ascending tie-break would put the relevant d10 at rank 2 and give a reciprocal rank of 1/2 instead of 1/3);
+      q2  a passage id on several lines (the reference's run dict keeps the LAST score, :325: `runs[query][passage] = rel` -- this is
+          what the "0 ... 0" filler lines of a de-duplicated run do), graded judgements > 1 (ndcg_cut_3 takes the grade as the gain
+          and the ideal ranking over ALL judged documents, retrieved or not), and rel_threshold binarising recall / MRR only;
+      q3  no relevant document at all: every measure 0, and the query still counts in the averages;
+      q4  in the run but not judged: skipped;  q5  judged but not in the run: ignored (pytrec_eval evaluates the run's queries)."""
+    from haconvdr_amd.trec import print_trec_res
+    qrel = [("q1", "d10", 1), ("q1", "d2", 0), ("q1", "d1", 1),
+            ("q2", "p5", 3), ("q2", "p7", 1), ("q2", "p8", 2),
+            ("q3", "a", 0), ("q3", "b", 0),
+            ("q5", "zz", 1)]
+    (tmp_path / "qrel.trec").write_text("".join(f"{q} 0 {p} {r}\n" for q, p, r in qrel))
+    run = [("q1", "d9", 5), ("q1", "d10", 5), ("q1", "d2", 7), ("q1", "d1", 1),
+           ("q2", "p5", 199), ("q2", "p7", 198), ("q2", "p5", 197), ("q2", "0", 196), ("q2", "0", 195),
+           ("q3", "a", 3), ("q3", "b", 2),
+           ("q4", "w", 9)]
+    (tmp_path / "run.trec").write_text("".join(f"{q} Q0 {p} {i + 1} {s} {float(s)} ance\n" for i, (q, p, s) in enumerate(run)))
+    # q1: ranking d2, d9, d10, d1 -> RR 1/3, recall 2/2, DCG@3 = 1 / log2(4), ideal 1 + 1 / log2(3)                    -> 0.30657360
+    # q2: ranking p7 (198), p5 (197), 0 (195) -> RR 1, recall 2/3, DCG@3 = 1 + 3 / log2(3), ideal 3 + 2 / log2(3) + 1 / 2  -> 0.60749152
+    # q3: zeros.   Averages over q1, q2, q3, in percent, 5 places:
+    assert print_trec_res(str(tmp_path / "run.trec"), str(tmp_path / "qrel.trec")) == \
+        {"MRR": 44.44444, "NDCG@3": 30.46884, "Recall@10": 55.55556, "Recall@100": 55.55556}
+    # rel_threshold = 2: q1 has no relevant document left, q2's are p5 (rank 2) and p8 (not retrieved); NDCG keeps the grades
+    assert print_trec_res(str(tmp_path / "run.trec"), str(tmp_path / "qrel.trec"), rel_threshold=2) == \
+        {"MRR": 16.66667, "NDCG@3": 30.46884, "Recall@10": 16.66667, "Recall@100": 16.66667}
+
+
 def test_get_args_defaults_follow_the_two_scripts():
     """src/test_HAConvDR_qrecc.py:386-414 / src/test_HAConvDR_topiocqa.py:386-414."""
     from haconvdr_amd import queries
