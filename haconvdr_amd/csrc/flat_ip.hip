@@ -1744,7 +1744,7 @@ struct DeviceIndex {
     }
 
     int run_scan(const Plan &pl, const float *q_dev, int64_t nq, int k, u32 g_first, u32 g_step, u32 n_items,
-                 const float *thr_init, u32 pos_base, int P, hipStream_t st, bool timed, const int *nq_dev = nullptr) {
+                 const float *thr_init, u32 pos_base, int P, hipStream_t st, bool timed, const int *nq_dev = nullptr, bool cleared = false) {
         ScanArgs a;
         a.nq_dev = nq_dev;
         a.segs = d_segs;
@@ -1764,9 +1764,11 @@ struct DeviceIndex {
         a.thr_glob = thrglob();
         a.partial = (u64 *)ws_partial.p;
         a.partial_cnt = (u32 *)ws_pcnt.p;
-        HAC_HIP(hipMemsetAsync(ws_pcnt.p, 0, (size_t)nq * 4, st));
         a.pos_base = pos_base;
-        HAC_TRY(clear_thrglob((size_t)pl.n_qtiles * pl.QT, st));
+        if (!cleared) {     // (the device-decided fallback's first chunk: gather_rows_kernel has cleared both)
+            HAC_HIP(hipMemsetAsync(ws_pcnt.p, 0, (size_t)nq * 4, st));
+            HAC_TRY(clear_thrglob((size_t)pl.n_qtiles * pl.QT, st));
+        }
         if (timed) {
             if (ev_used == ev_pool.size()) {
                 hipEvent_t a0, a1;
@@ -1804,7 +1806,7 @@ struct DeviceIndex {
     // the device and nq is the capacity everything is sized for (the prefilter's device-decided fallback): no threshold
     // seeding (fewer launches on a path that is empty in the common case), the scan's workgroups are shared among the live
     // query tiles (vgrid), and rows of keys_out beyond *nq_dev are left alone.
-    int search_keys_exact(const float *q_dev, int64_t nq, int k, u64 *keys_out, u32 pos_base, hipStream_t st, const int *nq_dev = nullptr) {
+    int search_keys_exact(const float *q_dev, int64_t nq, int k, u64 *keys_out, u32 pos_base, hipStream_t st, const int *nq_dev = nullptr, bool cleared = false) {
         if (nq == 0) return HAC_OK;
         if (((uintptr_t)q_dev & 15) != 0) return fail(HAC_ERR_INVALID, "search: query pointer must be 16-byte aligned");
         if ((uint64_t)pos_base + (uint64_t)ntotal > 0xFFFFFFFFull) return fail(HAC_ERR_UNSUPPORTED, "row positions exceed 32 bits");
@@ -1863,7 +1865,7 @@ struct DeviceIndex {
             snprintf(last_plan, sizeof last_plan, "scan16_kernel<W=%d> grid=(%d,%d) QT=%d C=%d lds=%zu seed=%d", SCAN_WAVES, pl.P,
                      pl.n_qtiles, pl.QT, pl.C, pl.lds_scan, thr_init ? 1 : 0);
         if (!nq_dev) plan_text_slot = -1;   // (last_plan is this search's text; older device-decided searches still deliver their counts)
-        HAC_TRY(run_scan(pl, q_dev, nq, k, 0, 1, G, thr_init, pos_base, pl.P, st, profiling, nq_dev));
+        HAC_TRY(run_scan(pl, q_dev, nq, k, 0, 1, G, thr_init, pos_base, pl.P, st, profiling, nq_dev, cleared));
         // the workgroups' survivors sit densely per query: radix select of the k best, one sort of k keys
         const int np2 = (int)next_pow2((u32)k);
         select_keys_kernel<<<dim3((unsigned)nq), dim3(256), (size_t)np2 * 8, st>>>((const u64 *)ws_partial.p, (size_t)pl.P * k,
@@ -1967,7 +1969,7 @@ struct DeviceIndex {
         HAC_TRY(ws_stat.reserve(16));
         HAC_TRY(ws_thr.reserve((size_t)chunk * 4));
         HAC_TRY(fb_reserve((size_t)nq + 8));
-        HAC_HIP(hipMemsetAsync(ws_stat.p, 0, 16, st));
+        // (ws_stat: cleared by the first chunk's split_queries_kernel)
 
         ScanArgs a{};
         a.segs = d_segs;
@@ -2002,14 +2004,15 @@ struct DeviceIndex {
             float *delta_c = (float *)ws_delta.p + off;
             u64 *akeys_c = (u64 *)ws_akeys.p + (size_t)off * K2;
             split_queries_kernel<<<dim3((unsigned)nq_pad), dim3(192), 0, st>>>(reinterpret_cast<const float4 *>(qc), (int)n, K4, terms,
-                                                                              (const u32 *)ws_norm.p, (h16 *)ws_qsplit.p, delta_c);
+                                                                              (const u32 *)ws_norm.p, (h16 *)ws_qsplit.p, delta_c, (u32 *)ws_pcnt.p,
+                                                                              (u32 *)ws_thrglob.p, (u32)std::max(0, tune.debug_max_pass),
+                                                                              off == 0 ? (u32 *)ws_stat.p : nullptr);
             HAC_HIP(hipGetLastError());
             a.q = reinterpret_cast<const float4 *>(qc);
             a.nq = (int)n;
             sp.delta = delta_c;
             sp.pstride = pstride;
-            HAC_HIP(hipMemsetAsync(ws_pcnt.p, 0, (size_t)n * 4, st));
-            HAC_TRY(clear_thrglob((size_t)nq_pad, st));
+            // (ws_pcnt, the thresholds and their control words: cleared by split_queries_kernel)
             if (profiling) {
                 if (ev_used == ev_pool.size()) {
                     hipEvent_t a0, a1;
@@ -2114,15 +2117,23 @@ struct DeviceIndex {
             compact_failed_kernel<<<dim3(1), dim3(256), 0, st>>>((const u32 *)ws_fail.p, (int)nq, (int *)fbidx.p, chunk_cnt, n_fchunks, (int)QUERY_CHUNK);
             HAC_HIP(hipGetLastError());
             const int *nf_dev = (const int *)ws_stat.p;
-            gather_rows_kernel<<<dim3((unsigned)(((long)nq * K4 + 255) / 256)), dim3(256), 0, st>>>(
-                reinterpret_cast<const float4 *>(q_dev), (const int *)fbidx.p, (int)nq, K4, (float4 *)fbq.p, nf_dev);
+            // (the first fallback chunk's survivor counts and thresholds are cleared by gather_rows_kernel: sized from that chunk's plan)
+            Plan pl0;
+            const int64_t n0 = std::min<int64_t>(QUERY_CHUNK, nq);
+            HAC_TRY(make_plan(n0, k, G, pl0));
+            const int n_thr0 = pl0.n_qtiles * pl0.QT + THR_CTL_WORDS;
+            HAC_TRY(ws_pcnt.reserve((size_t)n0 * 4));
+            HAC_TRY(ws_thrglob.reserve((size_t)n_thr0 * 4));
+            gather_rows_kernel<<<dim3((unsigned)((std::max<long>((long)nq * K4, n_thr0) + 255) / 256)), dim3(256), 0, st>>>(
+                reinterpret_cast<const float4 *>(q_dev), (const int *)fbidx.p, (int)nq, K4, (float4 *)fbq.p, nf_dev, (u32 *)ws_pcnt.p, (int)n0,
+                (u32 *)ws_thrglob.p, n_thr0, (u32)std::max(0, tune.debug_max_pass));
             HAC_HIP(hipGetLastError());
             const bool prof = profiling;
             profiling = false;   // timed kernels of a search: the prefilter's scans
             int rc = HAC_OK;
             for (int c = 0; c < n_fchunks && rc == HAC_OK; ++c) {
                 const int64_t off = (int64_t)c * QUERY_CHUNK, n = std::min<int64_t>(QUERY_CHUNK, nq - off);
-                rc = search_keys_exact((const float *)fbq.p + (size_t)off * d, n, k, (u64 *)fbkeys.p + (size_t)off * k, pos_base, st, chunk_cnt + c);
+                rc = search_keys_exact((const float *)fbq.p + (size_t)off * d, n, k, (u64 *)fbkeys.p + (size_t)off * k, pos_base, st, chunk_cnt + c, c == 0);
             }
             profiling = prof;
             HAC_TRY(rc);
