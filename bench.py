@@ -571,7 +571,7 @@ def main():
                 extras["north_star_10M"]["verify"] = verify
                 # the like-for-like anchor of this series, measured on these very GPUs: the FULL step -- all nq queries encoded on
                 # this GPU, searched over this GPU's shard, no collective -- i.e. what the N = 1 line calls cfg4_shard_step
-                if enc is not None and (not args.rows or args.extras == "verify"):
+                if enc is not None:
                     tok_all, _ = synth.token_batch(0x70C, nq, Lq, fixed_len=Lq)
                     ids_all = torch.from_numpy(tok_all.astype(np.int64)).to(dev)
                     mask_all = torch.ones_like(ids_all)
@@ -587,7 +587,7 @@ def main():
                     extras["cfg4_shard_step"] = {"queries_per_sec": round(nq / t_loc, 1), "ms_per_step": round(t_loc * 1e3, 3), "rows_per_gpu": n_local,
                                                  "queries_per_step": nq, "min_over_ranks": round(float(rmin.item()), 1), "max_over_ranks": round(float(rmax.item()), 1),
                                                  "what": "the N = 1 anchor of this series measured on THIS run's GPUs: every rank encodes all the step's queries and "
-                                                         "searches its own 6.75M-row shard, no collective (rank 0's figure; min / max over the ranks beside it)"}
+                                                         "searches its own shard (rows_per_gpu; 6.75M at the default size), no collective (rank 0's figure; min / max over the ranks beside it)"}
                     del ids_all, mask_all
             else:
                 del idx2, srch2
