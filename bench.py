@@ -722,7 +722,7 @@ def passage_block_ownership_check(np, torch, dist, synth, enc, rank, world, barr
 
 
 # ------------------------------------------------------------------------------ committed PMC passes (roofline.traffic)
-KERNEL_SOURCES = ("flat_ip.hip", "scan_split.inc", "encoder.hip", "gemm8.inc")
+KERNEL_SOURCES = ("flat_ip.hip", "scan_split.inc", "encoder.hip", "gemm8.inc", "attn_pipe.inc")
 
 
 def kernel_sources_sha256():

@@ -1616,7 +1616,7 @@ struct DeviceIndex {
     // or capturing by the time someone asks.  Back-to-back device-decided searches each take their own (words, event) slot of
     // a small ring (with one slot, a search issued before the previous one had completed overwrote its words and
     // that search's fallback count never reached split_fallback_queries); when every slot is pending the new search's words are not collected.
-    static constexpr int PLAN_RING = 8;
+    static constexpr int PLAN_RING = 32;
     hipEvent_t ev_plan[PLAN_RING] = {};
     u32 *h_plan = nullptr;     // pinned [PLAN_RING][2]: (queries that fell back, max err / bound as float bits)
     bool slot_pending[PLAN_RING] = {};

@@ -1,7 +1,8 @@
 """Development: the two latency-bound shapes under rocprofv3 --kernel-trace --stats (per-kernel durations):
   enc : ANCE forward of B x L fully padded queries, plain launches (graph = off), N repetitions
   cfg2: 1000 pre-encoded queries over a 1M x 768 corpus (BASELINE configs[1]), N repetitions
-  python tools/latency_profile.py enc 4 512 50 | cfg2 30"""
+  single: one query over the same corpus
+  python tools/latency_profile.py enc 4 512 50 | cfg2 30 | single 200"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -40,14 +41,16 @@ def main():
         xs = torch.cat([bench.gen_rows(0xC0FFEE + c, bench.CH, dev) for c in range(8)])
         idx.add_tensor(xs)
         q = bench.gen_rows(0xBEEF, 1000, dev)
-        for _ in range(3):
+        if what == "single":        # one query over the same 1M resident rows (the image is there from the third search on)
+            q = q[:1].contiguous()
+        for _ in range(5):
             idx.search_tensor(q, 100)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(N):
             idx.search_tensor(q, 100)
         torch.cuda.synchronize()
-        print(f"cfg2: {(time.perf_counter() - t0) / N * 1e3:.4f} ms per search, {idx.last_plan()}")
+        print(f"{what}: {(time.perf_counter() - t0) / N * 1e3:.4f} ms per search, {idx.last_plan()}")
 
 
 if __name__ == "__main__":
