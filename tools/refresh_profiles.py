@@ -123,7 +123,7 @@ def main():
             sys.exit(f"scanh_kernel<1, false, 16> fetched {max(reads) / image:.3f} x the fp16 image in one of {len(reads)} searches (limit 1.15): "
                      "the query tiles of a row range no longer share their rows in the L2")
     for name, needle in (("qkv", "gemm8_kernel<0,"), ("out_proj", "gemm8_kernel<2, false>"), ("ffn_down", "gemm8_kernel<2, true>"),
-                         ("attention", "attention_stream_kernel<16>"),
+                         ("attention", "attention_pipe_kernel<8>"), ("attention_one_block", "attention_stream_kernel<16>"),
                          ("rescore", "rescore_kernel")):
         t = traffic(needle)
         if t:
