@@ -1668,10 +1668,10 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
         const bool att_one = att_qs > 1 && L32 > 256;   // few sequences: one launch (an empty second one is 5 us of a ~100-us layer)
         AttnArgs a{q, k, vt, ctx, s, last ? 1 : 0, att_qs, att_one ? 1 : 0, nullptr, nullptr, 0};
         if (li == 0) e->plan_attn_pipe = 0;
-        // (measured, 512 sequences of one length: 512 rows 0.587 against 0.603 ms for the one-block kernel, 384 rows 0.413 / 0.389, 256 rows
-        // 0.215 / 0.182 -- an item's ~15 k cycles of start-up and drain weigh more the shorter it is: the woven form takes the long class of
-        // batches padded beyond 384 rows, the one-block kernel everything else; same bits either way)
-        const bool att_pipe = e->attn_mode == 0 && e->attn_pipe != 0 && att_qs == 1 && !last && (L32 > 384 || e->attn_pipe > 0);
+        // (measured, 512 sequences of one length, woven / one-block: 512 rows 0.475 / 0.589 ms, 448 rows 0.413 / 0.507, 384 rows 0.313 / 0.373;
+        // 256 rows 0.174 / 0.174, 128 rows 0.086 / 0.086 -- the 8-wave instantiation wins wherever it applies, the 4-wave one ties: the woven
+        // form takes the long class (sequences of more than 256 rows), the one-block kernel the short class; same bits either way)
+        const bool att_pipe = e->attn_mode == 0 && e->attn_pipe != 0 && att_qs == 1 && !last && (L32 > 256 || e->attn_pipe > 0);
         if (att_pipe) {
             if (!e->plan_attn_pipe) {      // the forward's first woven layer: workspace, per-layer counts to zero (the flags are zero whenever no pass is pending)
                 HAC_TRY(e->ws_redo.reserve(((size_t)B * NH + 16) * 4));

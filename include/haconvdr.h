@@ -243,7 +243,7 @@ int hac_encoder_forward_device(hac_encoder *enc, const void *ids_dev, const void
  * 15; 0 = round 2's loop: same results bit for bit); "attn_qsplit" = "auto" (default) | "off" (with few sequences the streaming
  * attention kernel deals the query rows of a (sequence, head) item to 2..16 workgroups and runs both length classes in one launch;
  * same bits); "attn_pipe" = "auto" (default) | "off" | "all" (whole (sequence, head) items -- no query split, not the <s>-only last layer -- of sequences
- * longer than 256 rows in batches padded beyond 384 go through the kernel with two query blocks per wave, the softmax of one woven into the MFMAs of the
+ * longer than 256 rows go through the kernel with two query blocks per wave, the softmax of one woven into the MFMAs of the
  * other, followed by a fix-up pass of the one-block kernel over the items whose softmax reference has to move; "off": the one-block kernel
  * everywhere; "all" (tests): the woven form for every whole item of either length class; same bits); "g8_stagger" = "auto" (default) | "off" (the workgroups of the large-batch
  * QKV and out-projection GEMMs start in four phases, one per pair of XCDs, so that their epilogues do not reach HBM all at once;

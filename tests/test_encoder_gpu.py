@@ -241,7 +241,7 @@ def test_woven_attention_is_bit_identical_to_the_one_block_kernel(shape):
                 enc.set_option("attn_pipe", mode)
                 outs[mode] = enc(ids.astype(np.int32), mask.astype(np.int32))
                 plan = _plan(enc)
-                woven = mode == "all" or (mode == "auto" and L > 384)      # ("auto": the long class of batches padded beyond 384 rows)
+                woven = mode == "all" or (mode == "auto" and L > 256)      # ("auto": the long class -- batches padded beyond 256 rows have one)
                 assert plan["attn"] == "stream" and plan["attn_form"] == ("woven" if woven else "single"), plan
                 if woven:
                     assert enc.attention_redo() == 0
