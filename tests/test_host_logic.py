@@ -309,3 +309,59 @@ def test_no_packed_fp32_op_sel_form_in_any_kernel(tmp_path):
                 bad[name] = bad.get(name, 0) + 1
     assert not bad, bad
     assert seen_kernels > 40 and gemm8 == 6            # three epilogues x two loop forms were looked at
+
+def test_counted_wait_kernels_issue_exactly_the_vector_memory_operations_their_waits_assume(tmp_path):
+    """the LDS-landed RESID epilogue of gemm8 (gemm8.inc) and the woven attention kernel (attn_pipe.inc) derive every
+    `s_waitcnt vmcnt(N)` by hand from the wave's issue order.  One extra vector-memory instruction from a compiler upgrade -- a
+    pointer select turned into a load, a spill -- would make those waits too lax: stale LDS reads, wrong embeddings, no crash.  The
+    shipped library is disassembled and the counts the waits were derived from are asserted: no scratch access, no plain (non-LDS)
+    `global_load` at all in the kernels whose queue holds only DMAs and stores, and the exact number of LDS-DMA and store
+    instructions.  A change that moves these numbers must re-derive the waits (tables in the sources) and then update them here."""
+    import re
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    csrc = os.path.join(ROOT, "haconvdr_amd", "csrc")
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump in this image")
+    lib = os.path.join(csrc, "libhaconvdr.so")
+    assert os.path.exists(lib), "libhaconvdr.so is not built (python -c 'import __graft_entry__ as g; g.build()')"
+    shutil.copy(lib, tmp_path / "libhaconvdr.so")
+    subprocess.run([objdump, "--offloading", "libhaconvdr.so"], cwd=tmp_path, check=True, capture_output=True)
+    counts = {}
+    for c in sorted(f for f in os.listdir(tmp_path) if f.startswith("libhaconvdr.so.") and "gfx950" in f):
+        dis = subprocess.run([objdump, "-d", c], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
+        name = None
+        for line in dis.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.*)>:", line)
+            if m:
+                name = m.group(1)
+                continue
+            if name is None:
+                continue
+            k = counts.setdefault(name, {"dma": 0, "store": 0, "load": 0, "scratch": 0, "atomic": 0})
+            if "global_load_lds" in line:
+                k["dma"] += 1
+            elif re.search(r"\b(global|buffer|flat)_load", line):
+                k["load"] += 1
+            elif re.search(r"\b(global|buffer|flat)_store", line):
+                k["store"] += 1
+            elif "scratch_" in line:
+                k["scratch"] += 1
+            elif re.search(r"\b(global|buffer|flat)_atomic", line):
+                k["atomic"] += 1
+
+    def of(needle):
+        hit = [(n, v) for n, v in counts.items() if needle in n]
+        assert len(hit) == 1, (needle, [n for n, _ in hit])
+        return hit[0][1]
+    # gemm8_kernel<EPI8_RESID, SPLIT = true> (the shipped loop form): DMAs of the k-loop and of the epilogue's residual patch, 24 stores
+    assert of("gemm8_kernelILi2ELb1E") == {"dma": 82, "store": 24, "load": 0, "scratch": 0, "atomic": 0}
+    # attention_pipe_kernel<8> / <4>: Q / K / V pieces, 8 context stores + the (rare) flag store, one atomic (the layer's flag count)
+    for nw in (8, 4):
+        a = of(f"attention_pipe_kernelILi{nw}E")
+        assert a["load"] == 0 and a["scratch"] == 0 and a["store"] == 9 and a["atomic"] == 1, (nw, a)
+    # the one-block streaming kernels (counted waits as well; fix-up mode adds the flag store)
+    for wv in (16, 8):
+        a = of(f"attention_stream_kernelILi{wv}E")
+        assert a["load"] == 0 and a["scratch"] == 0 and a["store"] == 5, (wv, a)
