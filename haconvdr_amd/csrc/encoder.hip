@@ -1422,6 +1422,7 @@ struct hac_encoder {
     GrowBuf ws_redo;                      // [16] per-layer counts | [B * 12] item flags of the attention fix-up pass (attn_pipe.inc)
     GrowBuf ws_clk;                       // [4] u64: hac_encoder_last_clock
     bool clk_valid = false;
+    hipEvent_t clk_ev = nullptr;          // recorded behind the launch that wrote ws_clk: what hac_encoder_last_clock waits for (not the whole device)
 };
 
 namespace {
@@ -1730,6 +1731,10 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
             }
             HAC_TRY(prof_begin(e, 1 + HAC_ENC_CLASS_FFN_UP, st));
             launch8(epi_gelu, 2);
+            if (g8a.clk) {      // (class profiling is never on inside a captured forward: graph_usable)
+                if (!e->clk_ev) HAC_HIP(hipEventCreateWithFlags(&e->clk_ev, hipEventDisableTiming));
+                HAC_HIP(hipEventRecord(e->clk_ev, st));
+            }
             g8a.clk = nullptr;
             HAC_TRY(prof_end(e, 1 + HAC_ENC_CLASS_FFN_UP, st));
             g8a.n_groups = 1;
@@ -2020,6 +2025,7 @@ void hac_encoder_destroy(hac_encoder *e) {
     }
     drop_graphs(e);
     if (e->graph_done) (void)hipEventDestroy(e->graph_done);
+    if (e->clk_ev) (void)hipEventDestroy(e->clk_ev);
     for (GrowBuf *b : {&e->ws_x, &e->ws_xb, &e->ws_q, &e->ws_k, &e->ws_vt, &e->ws_ctx, &e->ws_y, &e->ws_h, &e->ws_seq, &e->ws_ids, &e->ws_mask, &e->ws_out, &e->ws_cls, &e->ws_stats, &e->ws_yb, &e->ws_part, &e->ws_idstats,
                        &e->ws_gids, &e->ws_gmask, &e->ws_gout, &e->ws_ksplit, &e->ws_identgb, &e->ws_clk, &e->ws_redo})
         b->release();
@@ -2263,7 +2269,10 @@ int hac_encoder_last_clock(hac_encoder *e, uint64_t out[2]) {
     if (!e->clk_valid || !e->ws_clk.p) return HAC_OK;
     DeviceGuard g(e->device);
     unsigned long long h[4] = {0, 0, 0, 0};
-    HAC_HIP(hipDeviceSynchronize());   // (not the stream of that launch: the caller may have destroyed it since)
+    // (the event behind that launch, not the launch's stream -- the caller may have destroyed it since -- and not the whole device:
+    // ADVICE r5)
+    if (e->clk_ev) HAC_HIP(hipEventSynchronize(e->clk_ev));
+    else HAC_HIP(hipDeviceSynchronize());
     HAC_HIP(hipMemcpy(h, e->ws_clk.p, sizeof h, hipMemcpyDeviceToHost));
     if (h[2] > h[0] && h[3] > h[1]) {
         out[0] = h[2] - h[0];
