@@ -2276,7 +2276,7 @@ struct hac_index {
 extern "C" {
 
 const char *hac_last_error(void) { return last_error_slot().c_str(); }
-const char *hac_version(void) { return "haconvdr-amd 0.5.0 (gfx950)"; }
+const char *hac_version(void) { return "haconvdr-amd 0.6.0 (gfx950)"; }
 
 int hac_index_create(int d, const int *device_ids, int n_dev, hac_index **out) {
     if (!out) return fail(HAC_ERR_INVALID, "hac_index_create: out is null");
