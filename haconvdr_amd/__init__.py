@@ -5,4 +5,4 @@ ANCE/RoBERTa encoder as hand-written gfx950 HIP kernels behind a C-ABI
 (include/haconvdr.h, built to haconvdr_amd/csrc/libhaconvdr.so).  There is no CPU
 fallback: every compute entry point raises if the HIP library is missing.
 """
-__version__ = "0.5.0"
+__version__ = "0.6.0"
