@@ -1420,6 +1420,16 @@ struct hac_encoder {
     GrowBuf ws_gids, ws_gmask, ws_gout;
     GrowBuf ws_identgb;                   // [2][768]: gamma = 1, beta = 0
     GrowBuf ws_redo;                      // [16] per-layer counts | [B * 12] item flags of the attention fix-up pass (attn_pipe.inc)
+    // Layers whose items mostly fail the woven kernel's check (near one-hot attention: a property of the weights more than of the batch) would
+    // pay for both kernels every time (measured with logits x 100: 28.4 against 14.4 ms per forward).  The per-layer counts of a forward come
+    // back through a pinned copy and an event nobody waits for; a later forward that finds them routes such layers through the one-block kernel
+    // at once (same bits either way) and tries the woven form again every 64th forward.
+    int *h_redo = nullptr;                // pinned [16]
+    hipEvent_t redo_ev = nullptr;
+    bool redo_pending = false;
+    long redo_items = 0;                  // items per layer (B x 12) of the forward whose counts are pending
+    unsigned pipe_skip_mask = 0;          // bit l: layer l goes straight to the one-block kernel
+    unsigned forwards_since_retry = 0;
     GrowBuf ws_clk;                       // [4] u64: hac_encoder_last_clock
     bool clk_valid = false;
     hipEvent_t clk_ev = nullptr;          // recorded behind the launch that wrote ws_clk: what hac_encoder_last_clock waits for (not the whole device)
@@ -1501,6 +1511,17 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
                 long rows_plan = 0) {
     const hac_encoder_config &c = e->cfg;
     const int L32 = (L + SEQ_ALIGN - 1) / SEQ_ALIGN * SEQ_ALIGN;
+    if (e->redo_pending && hipEventQuery(e->redo_ev) == hipSuccess) {      // the fix-up counts of an earlier forward have arrived (never waited for)
+        e->redo_pending = false;
+        for (int l = 0; l < 16; ++l)     // (a wave counts its item once, up to 8 waves per item: "most items" = more than two counts per item)
+            if ((long)e->h_redo[l] > 2 * e->redo_items) e->pipe_skip_mask |= 1u << l;
+    } else if (e->redo_pending) {
+        (void)hipGetLastError();
+    }
+    if (++e->forwards_since_retry >= 64) {
+        e->forwards_since_retry = 0;
+        e->pipe_skip_mask = 0;
+    }
     const long rows_max = rows_hint > 0 ? std::min<long>(rows_hint, (long)B * L32) : (long)B * L32;
     const long Mp = (rows_max + MT - 1) / MT * MT;
     HAC_TRY(e->ws_x.reserve((size_t)Mp * H * 4));
@@ -1672,7 +1693,8 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
         // (measured, 512 sequences of one length, woven / one-block: 512 rows 0.475 / 0.589 ms, 448 rows 0.413 / 0.507, 384 rows 0.313 / 0.373;
         // 256 rows 0.174 / 0.174, 128 rows 0.086 / 0.086 -- the 8-wave instantiation wins wherever it applies, the 4-wave one ties: the woven
         // form takes the long class (sequences of more than 256 rows), the one-block kernel the short class; same bits either way)
-        const bool att_pipe = e->attn_mode == 0 && e->attn_pipe != 0 && att_qs == 1 && !last && (L32 > 256 || e->attn_pipe > 0);
+        const bool att_pipe = e->attn_mode == 0 && e->attn_pipe != 0 && att_qs == 1 && !last && (L32 > 256 || e->attn_pipe > 0) &&
+                              !(e->attn_pipe < 0 && ((e->pipe_skip_mask >> li) & 1u));      // ("all" pins the woven form: tests of the fix-up pass)
         if (att_pipe) {
             if (!e->plan_attn_pipe) {      // the forward's first woven layer: workspace, per-layer counts to zero (the flags are zero whenever no pass is pending)
                 HAC_TRY(e->ws_redo.reserve(((size_t)B * NH + 16) * 4));
@@ -1794,6 +1816,19 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
     cls_head_proj_kernel<<<dim3((unsigned)((B + CLS_SB - 1) / CLS_SB), H / head_ns), dim3(256), 0, st>>>(x_c, s, 1, B, e->wh, e->bh, y_c, head_ns);
     cls_head_norm_kernel<<<dim3((unsigned)B), dim3(256), 0, st>>>(y_c, s, e->ng, e->nb, 1e-5f, out_dev);
     HAC_HIP(hipGetLastError());
+    if (e->plan_attn_pipe && e->attn_pipe < 0 && !e->redo_pending) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {
+            if (!e->h_redo) HAC_HIP(hipHostMalloc((void **)&e->h_redo, 64, hipHostMallocDefault));
+            if (!e->redo_ev) HAC_HIP(hipEventCreateWithFlags(&e->redo_ev, hipEventDisableTiming));
+            HAC_HIP(hipMemcpyAsync(e->h_redo, e->ws_redo.p, 64, hipMemcpyDeviceToHost, st));
+            HAC_HIP(hipEventRecord(e->redo_ev, st));
+            e->redo_pending = true;
+            e->redo_items = (long)B * NH;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     e->plan_sub_batches += 1;
     e->plan_rows += Mp;
     e->plan_gemm = g8 ? "gemm8" : (big ? "classic256" : "classic128");
@@ -2026,6 +2061,11 @@ void hac_encoder_destroy(hac_encoder *e) {
     drop_graphs(e);
     if (e->graph_done) (void)hipEventDestroy(e->graph_done);
     if (e->clk_ev) (void)hipEventDestroy(e->clk_ev);
+    if (e->redo_ev) {
+        if (e->redo_pending) (void)hipEventSynchronize(e->redo_ev);     // (the pinned words are the target of a copy that may still be in flight)
+        (void)hipEventDestroy(e->redo_ev);
+    }
+    if (e->h_redo) (void)hipHostFree(e->h_redo);
     for (GrowBuf *b : {&e->ws_x, &e->ws_xb, &e->ws_q, &e->ws_k, &e->ws_vt, &e->ws_ctx, &e->ws_y, &e->ws_h, &e->ws_seq, &e->ws_ids, &e->ws_mask, &e->ws_out, &e->ws_cls, &e->ws_stats, &e->ws_yb, &e->ws_part, &e->ws_idstats,
                        &e->ws_gids, &e->ws_gmask, &e->ws_gout, &e->ws_ksplit, &e->ws_identgb, &e->ws_clk, &e->ws_redo})
         b->release();

@@ -244,8 +244,9 @@ int hac_encoder_forward_device(hac_encoder *enc, const void *ids_dev, const void
  * attention kernel deals the query rows of a (sequence, head) item to 2..16 workgroups and runs both length classes in one launch;
  * same bits); "attn_pipe" = "auto" (default) | "off" | "all" (whole (sequence, head) items -- no query split, not the <s>-only last layer -- of sequences
  * longer than 256 rows go through the kernel with two query blocks per wave, the softmax of one woven into the MFMAs of the
- * other, followed by a fix-up pass of the one-block kernel over the items whose softmax reference has to move; "off": the one-block kernel
- * everywhere; "all" (tests): the woven form for every whole item of either length class; same bits); "g8_stagger" = "auto" (default) | "off" (the workgroups of the large-batch
+ * other, followed by a fix-up pass of the one-block kernel over the items whose softmax reference has to move; in "auto" a layer whose items mostly needed
+ * that pass in an earlier forward goes through the one-block kernel directly, with a retry every 64th forward; "off": the one-block kernel
+ * everywhere; "all" (tests): the woven form for every whole item of either length class, always; same bits); "g8_stagger" = "auto" (default) | "off" (the workgroups of the large-batch
  * QKV and out-projection GEMMs start in four phases, one per pair of XCDs, so that their epilogues do not reach HBM all at once;
  * timing only, same bits).  Any other name or value is HAC_ERR_INVALID (never a
  * silent default).  HAC_ENC_GEMM gives the default of "gemm" and is read once, in hac_encoder_create.

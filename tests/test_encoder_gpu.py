@@ -288,6 +288,35 @@ def test_woven_attention_hands_rows_outside_the_window_to_the_fixup_pass(scale):
     enc.set_option("attn_pipe", "auto")
 
 
+def test_layers_whose_items_mostly_need_the_fixup_pass_skip_the_woven_kernel():
+    """Near one-hot attention (logits x 400 here) is a property of the weights: a layer whose items mostly fail the woven kernel's
+    check would pay for both kernels on every forward (measured: 28.4 against 14.4 ms per 1000 x 512 forward).  The per-layer counts
+    come back through a pinned copy nobody waits for; once they have arrived, "auto" routes such a layer through the one-block kernel
+    directly (plan: attn_form=single), with the same bits, and tries the woven form again every 64th forward; a model whose rows stay
+    in the window keeps the woven form."""
+    import torch
+    from haconvdr_amd import synth
+    enc, _ = _scaled_qk_encoder(20.0)
+    ids, lens = synth.token_batch(0x78, 200, 512, min_len=1)
+    mask = (np.arange(512)[None, :] < lens[:, None]).astype(np.int32)
+    first = enc(ids.astype(np.int32), mask.astype(np.int32))
+    assert _plan(enc)["attn_form"] == "woven" and enc.attention_redo() > 100
+    torch.cuda.synchronize()                       # (the counts have arrived by now; a forward never waits for them)
+    forms = []
+    for n in range(70):
+        out = enc(ids.astype(np.int32), mask.astype(np.int32))
+        forms.append(_plan(enc)["attn_form"])
+        if n < 3 or forms[-1] == "woven":
+            np.testing.assert_array_equal(out, first)
+        torch.cuda.synchronize()
+    assert forms[0] == "single" and forms.count("woven") == 1, forms      # ... one retry in 64 forwards, and it is sent back at once
+    calm = encoder(2, 0.08)
+    for n in range(3):
+        calm(ids.astype(np.int32), mask.astype(np.int32))
+        torch.cuda.synchronize()
+        assert _plan(calm)["attn_form"] == "woven"
+
+
 @pytest.mark.parametrize("lo,hi,n_seq", [(1, 96, 700), (200, 300, 400), (257, 512, 300)])
 def test_streaming_attention_many_items_per_workgroup(lo, hi, n_seq):
     """The persistent attention kernels walk several (sequence, head) items per workgroup: one- and two-chunk items back to
