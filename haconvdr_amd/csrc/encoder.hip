@@ -1511,12 +1511,21 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
                 long rows_plan = 0) {
     const hac_encoder_config &c = e->cfg;
     const int L32 = (L + SEQ_ALIGN - 1) / SEQ_ALIGN * SEQ_ALIGN;
-    if (e->redo_pending && hipEventQuery(e->redo_ev) == hipSuccess) {      // the fix-up counts of an earlier forward have arrived (never waited for)
-        e->redo_pending = false;
-        for (int l = 0; l < 16; ++l)     // (a wave counts its item once, up to 8 waves per item: "most items" = more than two counts per item)
-            if ((long)e->h_redo[l] > 2 * e->redo_items) e->pipe_skip_mask |= 1u << l;
-    } else if (e->redo_pending) {
-        (void)hipGetLastError();
+    bool fw_capturing = false;           // (inside a stream capture -- the small-batch graphs -- an event query is an error that kills the capture)
+    {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
+        else fw_capturing = cs != hipStreamCaptureStatusNone;
+    }
+    if (e->redo_pending && !fw_capturing) {
+        const hipError_t qe = hipEventQuery(e->redo_ev);
+        if (qe == hipSuccess) {          // the fix-up counts of an earlier forward have arrived (never waited for)
+            e->redo_pending = false;
+            for (int l = 0; l < 16; ++l)     // (a wave counts its item once, up to 8 waves per item: "most items" = more than two counts per item)
+                if ((long)e->h_redo[l] > 2 * e->redo_items) e->pipe_skip_mask |= 1u << l;
+        } else {
+            (void)hipGetLastError();     // (not ready: the query's hipErrorNotReady must not become the next check's error)
+        }
     }
     if (++e->forwards_since_retry >= 64) {
         e->forwards_since_retry = 0;
@@ -1817,16 +1826,13 @@ int run_forward(hac_encoder *e, const IT *ids, const IT *mask, int B, int L, flo
     cls_head_norm_kernel<<<dim3((unsigned)B), dim3(256), 0, st>>>(y_c, s, e->ng, e->nb, 1e-5f, out_dev);
     HAC_HIP(hipGetLastError());
     if (e->plan_attn_pipe && e->attn_pipe < 0 && !e->redo_pending) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {
+        if (!fw_capturing) {
             if (!e->h_redo) HAC_HIP(hipHostMalloc((void **)&e->h_redo, 64, hipHostMallocDefault));
             if (!e->redo_ev) HAC_HIP(hipEventCreateWithFlags(&e->redo_ev, hipEventDisableTiming));
             HAC_HIP(hipMemcpyAsync(e->h_redo, e->ws_redo.p, 64, hipMemcpyDeviceToHost, st));
             HAC_HIP(hipEventRecord(e->redo_ev, st));
             e->redo_pending = true;
             e->redo_items = (long)B * NH;
-        } else {
-            (void)hipGetLastError();
         }
     }
     e->plan_sub_batches += 1;
